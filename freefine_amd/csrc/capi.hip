@@ -1,0 +1,335 @@
+// C ABI of libfreefine_hip.so (see include/freefine_hip.h).  Host-side launch glue only: argument validation,
+// tile selection, dynamic-LDS opt-in.  No allocation, no synchronisation, everything on the caller's stream.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/freefine_hip.h"
+#include "attention.h"
+#include "elementwise.h"
+#include "igemm.h"
+#include "norms.h"
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FFN_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return FFN_OK;
+}
+#define REQUIRE(cond, ...) \
+    do {                   \
+        if (!(cond)) return fail(FFN_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int grid_for(long n, int per_block = 256, int cap = 4096) {
+    long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+template <typename K>
+static int set_lds(K kernel, int bytes) {
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return fail(FFN_EHIP, "hipFuncSetAttribute(%d): %s", bytes, hipGetErrorString(e));
+    }
+    return FFN_OK;
+}
+
+extern "C" int ffn_version(void) { return 1; }
+extern "C" const char* ffn_last_error(void) { return g_err; }
+extern "C" int ffn_device_info(int device, char* name, int name_len) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(FFN_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (name && name_len > 0) {
+        strncpy(name, prop.gcnArchName, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    return prop.multiProcessorCount;
+}
+
+// ---- igemm -------------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int AMODE, bool SWAP>
+static int launch_igemm(hipStream_t s, const ffn_igemm_desc& d) {
+    constexpr int lds = 2 * (BM + BN) * 128;
+    auto kern = igemm_kernel<T, BM, BN, AMODE, SWAP>;
+    static bool lds_set = false;  // one opt-in per instantiation
+    if (!lds_set) {
+        int rc = set_lds(kern, lds);
+        if (rc) return rc;
+        lds_set = true;
+    }
+    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+    hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(256), lds, s, d);
+    return check_launch("igemm");
+}
+template <typename T, int AMODE, bool SWAP>
+static int dispatch_igemm_tile(hipStream_t s, const ffn_igemm_desc& d) {
+    // pick the largest tile that still gives the chip >= ~1 wave of workgroups (256 CUs, 2 workgroups/CU)
+    const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+    const long t12864 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64);
+    const bool geglu = d.flags & FFN_IG_GEGLU;
+    if (d.N > 64 && (t128 >= 384 || (d.N % 128 == 0 && t128 >= 256))) return launch_igemm<T, 128, 128, AMODE, SWAP>(s, d);
+    if (t12864 >= 256 || d.M >= 4096) return launch_igemm<T, 128, 64, AMODE, SWAP>(s, d);
+    (void)geglu;
+    return launch_igemm<T, 64, 64, AMODE, SWAP>(s, d);
+}
+template <typename T>
+static int dispatch_igemm(hipStream_t s, const ffn_igemm_desc& d) {
+    const bool tr = d.flags & FFN_IG_OUT_TRANSPOSED;
+    if (d.conv) {
+        if (tr) return fail(FFN_EINVAL, "igemm: transposed output is only supported for dense A");
+        return dispatch_igemm_tile<T, AMODE_CONV3, true>(s, d);
+    }
+    if (tr) return dispatch_igemm_tile<T, AMODE_DENSE, false>(s, d);
+    return dispatch_igemm_tile<T, AMODE_DENSE, true>(s, d);
+}
+extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
+    REQUIRE(d, "igemm: null descriptor");
+    REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "igemm: bad dtype %d", dtype);
+    const int epc = dtype == FFN_F32 ? 4 : 8, kstage = 8 * epc;
+    REQUIRE(d->A && d->W && d->out, "igemm: null A/W/out");
+    REQUIRE(aligned16(d->A) && aligned16(d->W) && aligned16(d->out), "igemm: A/W/out must be 16-byte aligned");
+    REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "igemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
+    REQUIRE(d->Kpad >= d->K && d->Kpad % kstage == 0, "igemm: Kpad=%d must be >= K=%d and a multiple of %d", d->Kpad, d->K, kstage);
+    REQUIRE(d->K % epc == 0, "igemm: K=%d must be a multiple of %d", d->K, epc);
+    REQUIRE(d->rows_per_batch > 0, "igemm: rows_per_batch must be > 0");
+    if (d->conv) {
+        REQUIRE(d->Cin % epc == 0, "igemm: Cin=%d must be a multiple of %d", d->Cin, epc);
+        REQUIRE(d->K == 9 * d->Cin, "igemm: conv K=%d != 9*Cin=%d", d->K, 9 * d->Cin);
+        REQUIRE(d->stride == 1 || d->stride == 2, "igemm: stride %d", d->stride);
+        REQUIRE(d->upsample == 0 || d->upsample == 1, "igemm: upsample %d", d->upsample);
+        REQUIRE(d->M % (d->Hout * d->Wout) == 0, "igemm: M=%d not a multiple of Hout*Wout", d->M);
+    } else {
+        REQUIRE(d->lda % epc == 0, "igemm: lda=%d must be a multiple of %d", d->lda, epc);
+    }
+    if (d->flags & FFN_IG_OUT_TRANSPOSED) {
+        REQUIRE(d->ldo % 4 == 0, "igemm: transposed ldo=%d must be a multiple of 4", d->ldo);
+        REQUIRE(!(d->flags & (FFN_IG_GEGLU | FFN_IG_OUT_F32 | FFN_IG_OUT_SILU)) && !d->residual && !d->rowbias,
+                "igemm: transposed output supports bias only");
+    } else {
+        REQUIRE(d->N % 4 == 0 && d->ldo % 4 == 0, "igemm: N=%d and ldo=%d must be multiples of 4", d->N, d->ldo);
+        if (d->residual) REQUIRE(d->ldr % 4 == 0, "igemm: ldr=%d must be a multiple of 4", d->ldr);
+        if (d->flags & FFN_IG_GEGLU) {
+            REQUIRE(d->N % 64 == 0, "igemm: GEGLU needs N %% 64 == 0 (N=%d)", d->N);
+            REQUIRE(!d->residual && !d->rowbias && !(d->flags & (FFN_IG_OUT_F32 | FFN_IG_OUT_SILU)), "igemm: GEGLU epilogue is exclusive");
+        }
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == FFN_F32 ? dispatch_igemm<float>(s, *d) : dispatch_igemm<bf16>(s, *d);
+}
+
+// ---- attention ---------------------------------------------------------------------------------------------------
+template <typename T, int DP, int QF>
+static int launch_attn(hipStream_t s, const ffn_attn_desc& d) {
+    constexpr int SZ = sizeof(T);
+    constexpr int lds = 64 * (DP * SZ + 16) + DP * (64 * SZ + 16);
+    auto kern = attn_kernel<T, DP, QF>;
+    static bool lds_set = false;
+    if (!lds_set) {
+        int rc = set_lds(kern, lds);
+        if (rc) return rc;
+        lds_set = true;
+    }
+    dim3 grid((d.S + 64 * QF - 1) / (64 * QF), d.heads, d.Bo);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d);
+    return check_launch("attn");
+}
+extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
+    REQUIRE(d, "attn: null descriptor");
+    REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "attn: bad dtype %d", dtype);
+    const int epc = dtype == FFN_F32 ? 4 : 8;
+    REQUIRE(d->q && d->k && d->vt && d->out, "attn: null q/k/vt/out");
+    REQUIRE(aligned16(d->q) && aligned16(d->k) && aligned16(d->vt) && aligned16(d->out), "attn: pointers must be 16-byte aligned");
+    REQUIRE(d->Bo > 0 && d->Bo <= FFN_ATT_MAXB, "attn: Bo=%d out of range (max %d)", d->Bo, FFN_ATT_MAXB);
+    REQUIRE(d->npass > 0 && d->npass <= FFN_ATT_MAXP, "attn: npass=%d out of range (max %d)", d->npass, FFN_ATT_MAXP);
+    REQUIRE(d->S > 0 && d->Sk > 0 && d->heads > 0 && d->D > 0, "attn: empty problem");
+    REQUIRE(d->D % epc == 0, "attn: D=%d must be a multiple of %d", d->D, epc);
+    REQUIRE(d->ldq % epc == 0 && d->ldk % epc == 0 && d->ldvt % epc == 0 && d->ldo % 4 == 0, "attn: leading dims must be chunk aligned");
+    REQUIRE(d->ldvt >= d->Sk, "attn: ldvt=%d < Sk=%d", d->ldvt, d->Sk);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int D = d->D;
+    if (dtype == FFN_F32) {
+        if (D <= 48) return launch_attn<float, 48, 2>(s, *d);
+        if (D <= 64) return launch_attn<float, 64, 2>(s, *d);
+        if (D <= 80) return launch_attn<float, 80, 2>(s, *d);
+        if (D <= 160) return launch_attn<float, 160, 1>(s, *d);
+    } else {
+        if (D <= 64) return launch_attn<bf16, 64, 2>(s, *d);
+        if (D <= 96) return launch_attn<bf16, 96, 2>(s, *d);
+        if (D <= 160) return launch_attn<bf16, 160, 1>(s, *d);
+    }
+    return fail(FFN_ENOSYS, "attn: head dim %d not supported (max 160; use the GEMM path)", D);
+}
+
+// ---- norms -------------------------------------------------------------------------------------------------------
+extern "C" int ffn_gn_nchunk(int HW) {
+    int n = HW / 64;
+    if (n < 1) n = 1;
+    if (n > 256) n = 256;
+    return n;
+}
+extern "C" int ffn_gn_stats(void* stream, int dtype, const void* x, const float* gamma, const float* beta, int B, int HW, int C,
+                            int G, float eps, float* partial_ws, float* scale, float* shift) {
+    REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "gn_stats: bad dtype");
+    const int epc = dtype == FFN_F32 ? 4 : 8;
+    REQUIRE(x && gamma && beta && partial_ws && scale && shift, "gn_stats: null pointer");
+    REQUIRE(C % epc == 0 && C % G == 0 && aligned16(x), "gn_stats: C=%d must be a multiple of %d and of G=%d", C, epc, G);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nchunk = ffn_gn_nchunk(HW);
+    const int ppc = (HW + nchunk - 1) / nchunk;
+    const int lds = 2 * C * (int)sizeof(float);
+    if (dtype == FFN_F32)
+        hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunk, B), dim3(256), lds, s, (const float*)x, partial_ws, HW, C, ppc);
+    else
+        hipLaunchKernelGGL(gn_partial_kernel<bf16>, dim3(nchunk, B), dim3(256), lds, s, (const bf16*)x, partial_ws, HW, C, ppc);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, s, partial_ws, gamma, beta, scale, shift, HW, C, G, nchunk, eps);
+    return check_launch("gn_stats");
+}
+extern "C" int ffn_gn_apply(void* stream, int dtype, const void* x, void* y, const float* scale, const float* shift, int B, int HW,
+                            int C, int silu) {
+    REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "gn_apply: bad dtype");
+    const int epc = dtype == FFN_F32 ? 4 : 8;
+    REQUIRE(x && y && scale && shift && C % epc == 0 && aligned16(x) && aligned16(y), "gn_apply: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long nch = (long)B * HW * (C / epc);
+    const int grid = grid_for(nch);
+    if (dtype == FFN_F32) {
+        if (silu) hipLaunchKernelGGL((gn_apply_kernel<float, true>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, nch, HW, C);
+        else hipLaunchKernelGGL((gn_apply_kernel<float, false>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, nch, HW, C);
+    } else {
+        if (silu) hipLaunchKernelGGL((gn_apply_kernel<bf16, true>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, scale, shift, nch, HW, C);
+        else hipLaunchKernelGGL((gn_apply_kernel<bf16, false>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, scale, shift, nch, HW, C);
+    }
+    return check_launch("gn_apply");
+}
+extern "C" int ffn_layernorm(void* stream, int dtype, const void* x, void* y, const float* gamma, const float* beta, int M, int C,
+                             float eps) {
+    REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "layernorm: bad dtype");
+    const int epc = dtype == FFN_F32 ? 4 : 8;
+    REQUIRE(x && y && gamma && beta && C % epc == 0 && aligned16(x) && aligned16(y), "layernorm: bad arguments");
+    const int cch = C / epc;
+    REQUIRE(cch <= 64 * 6, "layernorm: C=%d too large", C);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int grid = (M + 3) / 4;
+    if (dtype == FFN_F32) {
+        if (cch <= 128) hipLaunchKernelGGL((layernorm_kernel<float, 2>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, gamma, beta, M, C, eps);
+        else hipLaunchKernelGGL((layernorm_kernel<float, 6>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, gamma, beta, M, C, eps);
+    } else {
+        if (cch <= 128) hipLaunchKernelGGL((layernorm_kernel<bf16, 2>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, gamma, beta, M, C, eps);
+        else hipLaunchKernelGGL((layernorm_kernel<bf16, 6>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, gamma, beta, M, C, eps);
+    }
+    return check_launch("layernorm");
+}
+extern "C" int ffn_softmax_rows(void* stream, int dtype, const void* x, void* y, long M, int N, float scale) {
+    REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "softmax_rows: bad dtype");
+    REQUIRE(x && y && M > 0 && N > 0, "softmax_rows: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == FFN_F32) hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (const float*)x, (float*)y, N, scale);
+    else hipLaunchKernelGGL(softmax_rows_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, s, (const bf16*)x, (bf16*)y, N, scale);
+    return check_launch("softmax_rows");
+}
+
+// ---- scheduler / guidance ---------------------------------------------------------------------------------------
+extern "C" int ffn_cfg_masked(void* stream, const float* eps_u, const float* eps_c, const float* mask, float cfg, float* eps, long n,
+                              int HW) {
+    REQUIRE(eps_u && eps_c && eps && n > 0 && HW > 0, "cfg_masked: bad arguments");
+    hipLaunchKernelGGL(cfg_masked_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), eps_u, eps_c, mask, cfg, eps, n, HW);
+    return check_launch("cfg_masked");
+}
+extern "C" int ffn_ddim_inv_step(void* stream, const float* eps, const float* x, float c_bt, float c_at, float c_an, float c_bn,
+                                 float* x_next, float* pred_x0, long n) {
+    REQUIRE(eps && x && x_next && n > 0, "ddim_inv_step: bad arguments");
+    hipLaunchKernelGGL(ddim_inv_step_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), eps, x, c_bt, c_at, c_an, c_bn, x_next, pred_x0, n);
+    return check_launch("ddim_inv_step");
+}
+extern "C" int ffn_ddim_ctrl_step(void* stream, const ffn_ctrl_step_desc* d) {
+    REQUIRE(d && d->eps && d->x && d->x_prev && d->m && d->om, "ddim_ctrl_step: null pointer");
+    REQUIRE(d->rows > 0 && d->rows <= 8 && d->CHW > 0 && d->HW > 0 && d->CHW % d->HW == 0, "ddim_ctrl_step: bad shape");
+    hipLaunchKernelGGL(ddim_ctrl_step_kernel, dim3(grid_for((long)d->rows * d->CHW)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *d);
+    return check_launch("ddim_ctrl_step");
+}
+
+// ---- layout / misc -----------------------------------------------------------------------------------------------
+extern "C" int ffn_pack_nchw(void* stream, int dtype, const ffn_pack_desc* d) {
+    REQUIRE(d && d->src && d->dst && d->B > 0 && d->B <= 16 && d->CP >= d->Cl, "pack_nchw: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long n = (long)d->B * d->HW * d->CP;
+    if (dtype == FFN_F32) hipLaunchKernelGGL(pack_nchw_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, *d);
+    else if (dtype == FFN_BF16) hipLaunchKernelGGL(pack_nchw_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, s, *d);
+    else return fail(FFN_EINVAL, "pack_nchw: bad dtype");
+    return check_launch("pack_nchw");
+}
+extern "C" int ffn_nhwc_to_nchw_f32(void* stream, const float* src, float* dst, int B, int HW, int C, int ld) {
+    REQUIRE(src && dst && B > 0 && HW > 0 && C > 0 && ld >= C, "nhwc_to_nchw_f32: bad arguments");
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(grid_for((long)B * HW * C)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, B, HW, C, ld);
+    return check_launch("nhwc_to_nchw_f32");
+}
+extern "C" int ffn_concat(void* stream, int dtype, const void* a, const void* b, void* out, long rows, int C1, int C2) {
+    REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "concat: bad dtype");
+    const int epc = dtype == FFN_F32 ? 4 : 8;
+    REQUIRE(a && b && out && C1 % epc == 0 && C2 % epc == 0 && aligned16(a) && aligned16(b) && aligned16(out), "concat: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long n = rows * ((C1 + C2) / epc);
+    if (dtype == FFN_F32) hipLaunchKernelGGL(concat_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)out, rows, C1, C2);
+    else hipLaunchKernelGGL(concat_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16*)a, (const bf16*)b, (bf16*)out, rows, C1, C2);
+    return check_launch("concat");
+}
+extern "C" int ffn_timestep_embed(void* stream, int dtype, const float* t_dev, const float* freq, void* out, int B, int half, int flip) {
+    REQUIRE(t_dev && freq && out && B > 0 && half > 0, "timestep_embed: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int n = B * 2 * half;
+    if (dtype == FFN_F32) hipLaunchKernelGGL(timestep_embed_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, t_dev, freq, (float*)out, B, half, flip);
+    else if (dtype == FFN_BF16) hipLaunchKernelGGL(timestep_embed_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, s, t_dev, freq, (bf16*)out, B, half, flip);
+    else return fail(FFN_EINVAL, "timestep_embed: bad dtype");
+    return check_launch("timestep_embed");
+}
+extern "C" int ffn_transpose(void* stream, int dtype, const void* src, void* dst, int B, int R, int C, int ld_src, int ld_dst) {
+    REQUIRE(src && dst && B > 0 && R > 0 && C > 0, "transpose: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((C + 31) / 32, (R + 31) / 32, B);
+    if (dtype == FFN_F32) hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (float*)dst, R, C, ld_src, ld_dst);
+    else if (dtype == FFN_BF16) hipLaunchKernelGGL(transpose_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src, (bf16*)dst, R, C, ld_src, ld_dst);
+    else return fail(FFN_EINVAL, "transpose: bad dtype");
+    return check_launch("transpose");
+}
+extern "C" int ffn_cast(void* stream, int src_dtype, int dst_dtype, const void* src, void* dst, long n) {
+    REQUIRE(src && dst && n > 0, "cast: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int grid = grid_for(n);
+    if (src_dtype == FFN_F32 && dst_dtype == FFN_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(grid), dim3(256), 0, s, (const float*)src, (bf16*)dst, n);
+    else if (src_dtype == FFN_BF16 && dst_dtype == FFN_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(grid), dim3(256), 0, s, (const bf16*)src, (float*)dst, n);
+    else if (src_dtype == FFN_F32 && dst_dtype == FFN_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n);
+    else if (src_dtype == FFN_BF16 && dst_dtype == FFN_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)src, (bf16*)dst, n);
+    else return fail(FFN_EINVAL, "cast: bad dtypes %d -> %d", src_dtype, dst_dtype);
+    return check_launch("cast");
+}
+extern "C" int ffn_image_to_nhwc(void* stream, int dtype, const uint8_t* img, void* dst, long npix, int CP) {
+    REQUIRE(img && dst && npix > 0 && CP >= 3, "image_to_nhwc: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int grid = grid_for(npix * CP);
+    if (dtype == FFN_F32) hipLaunchKernelGGL(image_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, s, img, (float*)dst, npix, CP);
+    else if (dtype == FFN_BF16) hipLaunchKernelGGL(image_to_nhwc_kernel<bf16>, dim3(grid), dim3(256), 0, s, img, (bf16*)dst, npix, CP);
+    else return fail(FFN_EINVAL, "image_to_nhwc: bad dtype");
+    return check_launch("image_to_nhwc");
+}
+extern "C" int ffn_nhwc_to_image(void* stream, int dtype, const void* src, float* dst, int B, int HW, int ld) {
+    REQUIRE(src && dst && B > 0 && HW > 0 && ld >= 3, "nhwc_to_image: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int grid = grid_for((long)B * 3 * HW);
+    if (dtype == FFN_F32) hipLaunchKernelGGL(nhwc_to_image_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, dst, B, HW, ld);
+    else if (dtype == FFN_BF16) hipLaunchKernelGGL(nhwc_to_image_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)src, dst, B, HW, ld);
+    else return fail(FFN_EINVAL, "nhwc_to_image: bad dtype");
+    return check_launch("nhwc_to_image");
+}

@@ -1,0 +1,118 @@
+// Common device helpers for the FreeFine gfx950 (CDNA4 / MI355X) kernels.
+//
+// Data model shared by every kernel in this library:
+//   * activations live in HBM as [B, H*W, C] ("NHWC", channel-contiguous) so that the conv
+//     blocks and the transformer blocks of the SD UNet read and write the SAME buffers with no
+//     transposes in between (the reference, src/utils/attention.py:246, 297, transposes NCHW<->NLC
+//     around every attention call);
+//   * the element type T is either float (parity mode: exact fp32 MFMA, fp32 storage) or bf16
+//     (fast mode: bf16 MFMA operands, fp32 accumulate, bf16 storage);
+//   * all matrix products go through 16x16 MFMA tiles.  A "chunk" is 16 bytes of the contraction
+//     (K) dimension = 4 floats or 8 bf16; one MFMA k-substep consumes a 64-byte K slab per row, i.e.
+//     4 chunks, chunk g supplied by lane group g = lane>>4.  With that convention the LDS byte
+//     geometry of a tile is identical for both element types and only DT<T>::mma differs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+struct bf16 {
+    uint16_t v;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even; a plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950).
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+template <typename T>
+struct DT;
+
+template <>
+struct DT<float> {
+    static constexpr int EPC = 4;  // elements per 16-byte chunk
+    static constexpr int ID = 0;
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    // one 64-byte K slab (4 chunks x 4 floats): four exact-fp32 16x16x4 MFMAs; MFMA i consumes element i
+    // of every lane group's chunk, so the hardware k index g maps to K element 4g+i for A and B alike.
+    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[0]), __uint_as_float(b[0]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[1]), __uint_as_float(b[1]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[2]), __uint_as_float(b[2]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[3]), __uint_as_float(b[3]), c, 0, 0, 0);
+    }
+    // unpack a chunk to floats / pack floats to a chunk (used by fused prologues)
+    __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
+        for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(c[i]);
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f) {
+        u32x4 c;
+        for (int i = 0; i < 4; ++i) c[i] = __float_as_uint(f[i]);
+        return c;
+    }
+};
+
+template <>
+struct DT<bf16> {
+    static constexpr int EPC = 8;
+    static constexpr int ID = 1;
+    __device__ static __forceinline__ float ld(const bf16* p) { return bf16_to_f32(p->v); }
+    __device__ static __forceinline__ void st(bf16* p, float v) { p->v = f32_to_bf16(v); }
+    __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c,
+                                                    0, 0, 0);
+    }
+    __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(c[i] << 16);
+            f[2 * i + 1] = __uint_as_float(c[i] & 0xffff0000u);
+        }
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f) {
+        u32x4 c;
+        for (int i = 0; i < 4; ++i)
+            c[i] = (uint32_t)f32_to_bf16(f[2 * i]) | ((uint32_t)f32_to_bf16(f[2 * i + 1]) << 16);
+        return c;
+    }
+};
+
+// store 4 consecutive elements of type T from 4 floats (16 B for float, 8 B for bf16)
+__device__ __forceinline__ void store4(float* p, const float* v) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ void store4(bf16* p, const float* v) {
+    u32x2 w;
+    w[0] = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    w[1] = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    *reinterpret_cast<u32x2*>(p) = w;
+}
+__device__ __forceinline__ void load4(const float* p, float* v) {
+    f32x4 w = *reinterpret_cast<const f32x4*>(p);
+    v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3];
+}
+__device__ __forceinline__ void load4(const bf16* p, float* v) {
+    u32x2 w = *reinterpret_cast<const u32x2*>(p);
+    v[0] = __uint_as_float(w[0] << 16);
+    v[1] = __uint_as_float(w[0] & 0xffff0000u);
+    v[2] = __uint_as_float(w[1] << 16);
+    v[3] = __uint_as_float(w[1] & 0xffff0000u);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// Bijective XCD-aware remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch), so give
+// every XCD a contiguous run of logical tiles (neighbouring tiles share operand panels -> L2 hits).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}

@@ -1,0 +1,159 @@
+// HBM-bound elementwise kernels of the FreeFine hot path (gfx950): masked CFG, DDIM inversion step, masked
+// DDIM/DDPM control step, layout packing, channel concat, timestep embedding, transposes, casts.
+#pragma once
+#include "common.h"
+#include "../../include/freefine_hip.h"
+
+// eps = eu + (cfg * (ec - eu)) * mask[hw]        (/root/reference/src/demo/model.py:605-611, 418-424, 778-785)
+// eps_u/eps_c/out: fp32 [rows, C, HW]; mask: float [HW] (already promoted exactly as torch would) or null (plain CFG, :608)
+__global__ __launch_bounds__(256) void cfg_masked_kernel(const float* __restrict__ eu, const float* __restrict__ ec,
+                                                         const float* __restrict__ mask, float cfg, float* __restrict__ out,
+                                                         long n, int HW) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float d = cfg * (ec[i] - eu[i]);
+        out[i] = eu[i] + (mask ? d * mask[i % HW] : d);
+    }
+}
+
+// DDIM inversion step (model.py:109-132): pred_x0 = (x - c_bt*eps)/c_at ; x_next = c_an*pred_x0 + c_bn*eps
+__global__ __launch_bounds__(256) void ddim_inv_step_kernel(const float* __restrict__ eps, const float* __restrict__ x,
+                                                            float c_bt, float c_at, float c_an, float c_bn,
+                                                            float* __restrict__ x_next, float* __restrict__ pred_x0, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float e = eps[i];
+        const float p0 = (x[i] - c_bt * e) / c_at;
+        x_next[i] = c_an * p0 + c_bn * e;
+        if (pred_x0) pred_x0[i] = p0;
+    }
+}
+
+// masked DDIM/DDPM control step (model.py:134-198).  Row b uses the mask iff row_masked[b]; other rows use mask==1,
+// (1-mask)==0 (model.py:172-174).  m / om are float [HW] holding mask and (1 - mask) evaluated in the mask's OWN dtype
+// on the host (uint8 wrap-around preserved).  Per-row coefficients: c_dirm[b] = sqrt(1-a_prev-std_b^2).
+typedef ffn_ctrl_step_desc CtrlStepParams;
+__global__ __launch_bounds__(256) void ddim_ctrl_step_kernel(const CtrlStepParams p) {
+    const long n = (long)p.rows * p.CHW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / p.CHW);
+        const int hw = (int)(i % p.HW);
+        const float e = p.eps[i];
+        const float mk = p.row_masked[b] ? p.m[hw] : 1.f;
+        const float omk = p.row_masked[b] ? p.om[hw] : 0.f;
+        const float p0 = (p.x[i] - p.c_bt * e) / p.c_at;
+        const float dirm = p.c_dirm[b] * e * mk;
+        const float dir = p.c_dir * e * omk + dirm;
+        float xp = p.c_ap * p0 + dir;
+        if (p.noise) xp = xp + p.stdv[b] * p.noise[i] * mk;
+        p.x_prev[i] = xp;
+        if (p.pred_x0) p.pred_x0[i] = p0;
+    }
+}
+
+// latents fp32 NCHW [Bsrc, Cl, HW] -> T NHWC [B, HW, CP] (channels >= Cl zero), row b reads src_row[b]
+typedef ffn_pack_desc PackParams;
+template <typename T>
+__global__ __launch_bounds__(256) void pack_nchw_kernel(const PackParams p) {
+    const long n = (long)p.B * p.HW * p.CP;
+    T* dst = reinterpret_cast<T*>(p.dst);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % p.CP);
+        const long t = i / p.CP;
+        const int hw = (int)(t % p.HW), b = (int)(t / p.HW);
+        float v = 0.f;
+        if (c < p.Cl) v = p.src[((long)p.src_row[b] * p.Cl + c) * p.HW + hw];
+        DT<T>::st(dst + i, v);
+    }
+}
+
+// fp32 NHWC [B, HW, C] (row stride ld) -> fp32 NCHW [B, C, HW]
+__global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                               int B, int HW, int C, int ld) {
+    const long n = (long)B * C * HW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int hw = (int)(i % HW);
+        const long t = i / HW;
+        const int c = (int)(t % C), b = (int)(t / C);
+        dst[i] = src[((long)b * HW + hw) * ld + c];
+    }
+}
+
+// out[r, 0:C1] = a[r, :], out[r, C1:C1+C2] = b[r, :]   (skip-connection concat of the UNet up path), 16-byte chunks
+template <typename T>
+__global__ __launch_bounds__(256) void concat_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                                                     long rows, int C1, int C2) {
+    constexpr int EPC = DT<T>::EPC;
+    const int c1 = C1 / EPC, c2 = C2 / EPC, ct = c1 + c2;
+    const long n = rows * ct;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / ct;
+        const int c = (int)(i - r * ct);
+        const u32x4 v = (c < c1) ? *reinterpret_cast<const u32x4*>(a + r * C1 + c * EPC)
+                                 : *reinterpret_cast<const u32x4*>(b + r * C2 + (c - c1) * EPC);
+        *reinterpret_cast<u32x4*>(out + r * (C1 + C2) + c * EPC) = v;
+    }
+}
+
+// sinusoidal timestep embedding (diffusers Timesteps: flip_sin_to_cos -> [cos | sin]); t read from device memory so
+// a captured hipGraph can be replayed with a new timestep.  freq[j] = exp(-ln(10000) * j / (half - shift)) from host.
+template <typename T>
+__global__ void timestep_embed_kernel(const float* __restrict__ t_dev, const float* __restrict__ freq, T* __restrict__ out,
+                                      int B, int half, int flip) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 2 * half) return;
+    const int j = i % (2 * half);
+    const float t = *t_dev;
+    const int jj = j < half ? j : j - half;
+    const float a = t * freq[jj];
+    const bool want_cos = flip ? (j < half) : (j >= half);
+    DT<T>::st(out + i, want_cos ? cosf(a) : sinf(a));
+}
+
+// [B, R, C] -> [B, C, R] through a 32x32 LDS tile
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int R, int C,
+                                                        int ld_src, int ld_dst) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? DT<T>::ld(src + ((long)b * R + r) * ld_src + c) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < R && c < C) DT<T>::st(dst + ((long)b * C + c) * ld_dst + r, tile[tx][i]);
+    }
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) DT<TD>::st(dst + i, DT<TS>::ld(src + i));
+}
+
+// image pre/post for the VAE bracket (model.py:1282-1288, 270-280)
+// uint8 HWC [B,HW,3] -> T NHWC [B,HW,CP]: v/127.5 - 1
+template <typename T>
+__global__ __launch_bounds__(256) void image_to_nhwc_kernel(const uint8_t* __restrict__ img, T* __restrict__ dst, long npix, int CP) {
+    const long n = npix * CP;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % CP);
+        const long px = i / CP;
+        float v = 0.f;
+        if (c < 3) v = (float)img[px * 3 + c] / 127.5f - 1.0f;
+        DT<T>::st(dst + i, v);
+    }
+}
+// decoder output T NHWC [B,HW,ld] -> fp32 NCHW [B,3,HW] in [0,1]: clamp(x/2+0.5)
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_image_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int HW, int ld) {
+    const long n = (long)B * 3 * HW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int hw = (int)(i % HW);
+        const long t = i / HW;
+        const int c = (int)(t % 3), b = (int)(t / 3);
+        float v = DT<T>::ld(src + ((long)b * HW + hw) * ld + c) / 2.f + 0.5f;
+        dst[i] = fminf(fmaxf(v, 0.f), 1.f);
+    }
+}

@@ -1,0 +1,189 @@
+// GroupNorm / LayerNorm / row-softmax for [B, HW, C] (channel-contiguous) activations, gfx950.
+// HBM-bound kernels: 16-byte vector accesses, fp32 statistics (final group reduction in fp64).
+//
+// GroupNorm(32 groups) is split into (1) per-channel partial sums over pixel chunks, (2) a tiny finalize
+// that turns them into per-(batch, channel) scale/shift, (3) an elementwise apply with optional SiLU.
+// Replaces torch.nn.GroupNorm + SiLU inside diffusers ResnetBlock2D / Transformer2DModel / conv_norm_out
+// (reached from /root/reference/src/utils/attention.py:105-214).
+#pragma once
+#include "common.h"
+
+// ---- (1) partial sums: grid (nchunk, B), 256 threads ------------------------------------------------------
+// partial[b][chunk][c][2] = (sum, sumsq) over the chunk's pixels
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, float* __restrict__ partial, int HW,
+                                                         int C, int pix_per_chunk) {
+    constexpr int EPC = DT<T>::EPC;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ls = reinterpret_cast<float*>(smem);  // [C][2]
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int cch = C / EPC;                 // 16-byte chunks per pixel
+    const int cols = min(cch, 256);          // chunk columns handled concurrently
+    const int ppi = max(1, 256 / cch);       // pixels in flight per iteration
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * C; i += 256) ls[i] = 0.f;
+    __syncthreads();
+    const int p0 = chunk * pix_per_chunk;
+    const int p1 = min(HW, p0 + pix_per_chunk);
+    for (int cbase = 0; cbase < cch; cbase += 256) {
+        const int cc = cbase + tid % cols, pp = tid / cols;
+        if (cc >= cch || pp >= ppi) continue;
+        float s[EPC], ss[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s[e] = ss[e] = 0.f;
+        for (int px = p0 + pp; px < p1; px += ppi) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + ((long)b * HW + px) * C + cc * EPC);
+            float f[EPC];
+            DT<T>::unpack(v, f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                s[e] += f[e];
+                ss[e] += f[e] * f[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            atomicAdd(&ls[2 * (cc * EPC + e)], s[e]);
+            atomicAdd(&ls[2 * (cc * EPC + e) + 1], ss[e]);
+        }
+    }
+    __syncthreads();
+    float* dst = partial + ((long)b * nchunk + chunk) * 2 * C;
+    for (int i = tid; i < 2 * C; i += 256) dst[i] = ls[i];
+}
+
+// ---- (2) finalize: grid (G, B), 64 threads: scale[b][c] = rstd*gamma[c], shift[b][c] = beta[c]-mean*rstd*gamma[c]
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ scale,
+                                                         float* __restrict__ shift, int HW, int C, int G, int nchunk,
+                                                         float eps) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int cg = C / G;
+    double s = 0.0, ss = 0.0;
+    for (int i = lane; i < nchunk * cg; i += 64) {
+        const int ch = i / cg, c = g * cg + (i - ch * cg);
+        const float* src = partial + (((long)b * nchunk + ch) * C + c) * 2;
+        s += (double)src[0];
+        ss += (double)src[1];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        ss += __shfl_xor(ss, off);
+    }
+    const double n = (double)HW * cg;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float fmean = (float)mean;
+    for (int i = lane; i < cg; i += 64) {
+        const int c = g * cg + i;
+        const float sc = rstd * gamma[c];
+        scale[(long)b * C + c] = sc;
+        shift[(long)b * C + c] = beta[c] - fmean * sc;
+    }
+}
+
+// ---- (3) apply: y = act(x*scale[b][c] + shift[b][c]) ------------------------------------------------------
+template <typename T, bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       long nchunks_total, int HW, int C) {
+    constexpr int EPC = DT<T>::EPC;
+    const int cch = C / EPC;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks_total; i += (long)gridDim.x * 256) {
+        const long pix = i / cch;
+        const int cc = (int)(i - pix * cch);
+        const int b = (int)(pix / HW);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + i * EPC);
+        float f[EPC];
+        DT<T>::unpack(v, f);
+        const float* sc = scale + (long)b * C + cc * EPC;
+        const float* sh = shift + (long)b * C + cc * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float t = f[e] * sc[e] + sh[e];
+            if (SILU) t = silu_exact(t);
+            f[e] = t;
+        }
+        *reinterpret_cast<u32x4*>(y + i * EPC) = DT<T>::pack(f);
+    }
+}
+
+// ---- LayerNorm over C per row; one wave per row, two-pass in registers --------------------------------------
+template <typename T, int MAXCH>  // MAXCH = max 16-byte chunks per lane
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int M, int C, float eps) {
+    constexpr int EPC = DT<T>::EPC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    const int cch = C / EPC;
+    float f[MAXCH][EPC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int cc = lane + 64 * i;
+        if (cc < cch) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + (long)row * C + cc * EPC);
+            DT<T>::unpack(v, f[i]);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) s += f[i][e];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int cc = lane + 64 * i;
+        if (cc < cch) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float d = f[i][e] - mean;
+                ss += d * d;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    const float rstd = 1.0f / sqrtf(ss / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int cc = lane + 64 * i;
+        if (cc < cch) {
+            float o[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int c = cc * EPC + e;
+                o[e] = (f[i][e] - mean) * rstd * gamma[c] + beta[c];
+            }
+            *reinterpret_cast<u32x4*>(y + (long)row * C + cc * EPC) = DT<T>::pack(o);
+        }
+    }
+}
+
+// ---- row softmax (VAE mid-block single-head attention path: scores materialised once, 2 calls per image) ----
+// in: fp32 or T scores [M][N] (already scaled), out: T probabilities.  One 256-thread block per row.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int N, float scale) {
+    __shared__ float red[8];
+    const long row = blockIdx.x;
+    const T* xr = x + row * N;
+    T* yr = y + row * N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = -1e30f;
+    for (int i = tid; i < N; i += 256) m = fmaxf(m, DT<T>::ld(xr + i) * scale);
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 0.f;
+    for (int i = tid; i < N; i += 256) s += expf(DT<T>::ld(xr + i) * scale - m);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) red[4 + wave] = s;
+    __syncthreads();
+    s = red[4] + red[5] + red[6] + red[7];
+    const float inv = 1.0f / s;
+    for (int i = tid; i < N; i += 256) DT<T>::st(yr + i, expf(DT<T>::ld(xr + i) * scale - m) * inv);
+}

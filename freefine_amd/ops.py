@@ -1,0 +1,357 @@
+"""Typed wrappers over the C ABI for torch device tensors (device memory + current stream only; no torch math).
+
+Activations are [B, HW, C] channel-contiguous tensors of dtype float32 ("parity mode") or bfloat16 ("fast mode").
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return L.FFN_F32
+    if t.dtype == torch.bfloat16:
+        return L.FFN_BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def epc(dtype):
+    return 4 if dtype == torch.float32 else 8
+
+
+def kstage(dtype):
+    return 8 * epc(dtype)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# weight packing (host side, once at load time)
+# ---------------------------------------------------------------------------------------------------------------
+def pack_linear(w, dtype):
+    """[N, K] -> [N, Kpad] zero padded, contiguous, dtype."""
+    n, k = w.shape
+    ks = kstage(dtype)
+    kpad = (k + ks - 1) // ks * ks
+    out = torch.zeros(n, kpad, dtype=dtype, device=w.device)
+    out[:, :k] = w.to(dtype)
+    return out
+
+
+def pack_conv3x3(w, dtype, cin_pad=None):
+    """[Cout, Cin, 3, 3] -> [Cout, Kpad], k = (ky*3+kx)*Cin_p + ci."""
+    cout, cin = w.shape[:2]
+    cp = cin_pad or cin
+    w2 = torch.zeros(cout, 3, 3, cp, dtype=torch.float32, device=w.device)
+    w2[..., :cin] = w.permute(0, 2, 3, 1).float()
+    return pack_linear(w2.reshape(cout, 9 * cp), dtype)
+
+
+def pack_geglu(w, b, dtype):
+    """GEGLU proj [2F, K] (+bias [2F]): interleave 16-row blocks hidden/gate so one lane holds both halves."""
+    f2, k = w.shape
+    f = f2 // 2
+    assert f % 16 == 0
+    idx = torch.arange(f, device=w.device).reshape(f // 16, 16)
+    order = torch.stack([idx, idx + f], dim=1).reshape(-1)  # [h0..h15, g0..g15, h16.., ...]
+    wp = pack_linear(w[order], dtype)
+    bp = None if b is None else b[order].float().contiguous()
+    return wp, bp
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# igemm
+# ---------------------------------------------------------------------------------------------------------------
+def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, rows_per_batch=None, silu=False,
+           geglu=False, out_f32=False, transposed_ld=None, alpha=1.0):
+    """out = x @ w[:, :K]^T (+bias ...).  x: [..., K] contiguous rows (M = prod of leading dims)."""
+    lib = L.load()
+    K = K if K is not None else x.shape[-1]
+    M = x.numel() // x.shape[-1]
+    N = w.shape[0]
+    d = L.IgemmDesc()
+    d.A, d.W = x.data_ptr(), w.data_ptr()
+    d.bias, d.rowbias, d.residual = _p(bias), _p(rowbias), _p(residual)
+    d.M, d.N, d.K, d.Kpad = M, N, K, w.shape[1]
+    d.lda = x.shape[-1]
+    d.rows_per_batch = rows_per_batch or M
+    d.ldrb = rowbias.shape[-1] if rowbias is not None else 0
+    flags = 0
+    n_out = N
+    if silu:
+        flags |= L.IG_OUT_SILU
+    if geglu:
+        flags |= L.IG_GEGLU
+        n_out = N // 2
+    if out_f32:
+        flags |= L.IG_OUT_F32
+    if transposed_ld is not None:
+        flags |= L.IG_OUT_TRANSPOSED
+        nb = M // d.rows_per_batch
+        if out is None:
+            out = torch.zeros(nb, N, transposed_ld, dtype=x.dtype, device=x.device)
+        d.ldo = transposed_ld
+    else:
+        if out is None:
+            out = torch.empty(*x.shape[:-1], n_out, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+        d.ldo = n_out
+    d.ldr = residual.shape[-1] if residual is not None else 0
+    d.out = out.data_ptr()
+    d.flags, d.alpha, d.conv = flags, alpha, 0
+    L.check(lib.ffn_igemm(_stream(), _dt(x), C.byref(d)), "ffn_igemm")
+    return out
+
+
+def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, out=None, residual=None, rowbias=None,
+            out_f32=False, Hout=None, Wout=None):
+    """x: [B, Hin*Win, Cin] NHWC; w: packed [Cout, Kpad]; returns [B, Hout*Wout, Cout]."""
+    lib = L.load()
+    He, We = (Hin * 2, Win * 2) if upsample else (Hin, Win)
+    if Hout is None:
+        Hout = (He + 2 * pad - 3) // stride + 1
+        Wout = (We + 2 * pad - 3) // stride + 1
+    N = w.shape[0]
+    d = L.IgemmDesc()
+    d.A, d.W = x.data_ptr(), w.data_ptr()
+    d.bias, d.rowbias, d.residual = _p(bias), _p(rowbias), _p(residual)
+    d.M, d.N, d.K, d.Kpad = B * Hout * Wout, N, 9 * Cin, w.shape[1]
+    d.lda = Cin
+    d.rows_per_batch = Hout * Wout
+    d.ldrb = rowbias.shape[-1] if rowbias is not None else 0
+    if out is None:
+        out = torch.empty(B, Hout * Wout, N, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    d.out, d.ldo = out.data_ptr(), N
+    d.ldr = residual.shape[-1] if residual is not None else 0
+    d.Hin, d.Win, d.Cin, d.Hout, d.Wout = Hin, Win, Cin, Hout, Wout
+    d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
+    d.flags, d.alpha, d.conv = (L.IG_OUT_F32 if out_f32 else 0), 1.0, 1
+    L.check(lib.ffn_igemm(_stream(), _dt(x), C.byref(d)), "ffn_igemm(conv)")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------------------------
+class AttnEntrySpec:
+    """One (pass, output-row) term of ffn_attn (see include/freefine_hip.h)."""
+    __slots__ = ("q_row", "kv_row", "w_const", "w_slope", "wq", "kmask", "qsel", "flags")
+
+    def __init__(self, q_row, kv_row, w_const=1.0, w_slope=0.0, wq=None, kmask=None, qsel=None, flags=0):
+        self.q_row, self.kv_row, self.w_const, self.w_slope = q_row, kv_row, w_const, w_slope
+        self.wq, self.kmask, self.qsel, self.flags = wq, kmask, qsel, flags
+
+
+def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=None, Bo=None):
+    """q: [Bq,S,C]; k: [Bk,Sk,C]; vt: [Bk,C,ldvt] (V transposed).  passes: list (per pass) of lists (per output
+    row) of AttnEntrySpec or None (= skipped).  passes=None -> plain attention, row b uses its own K/V."""
+    lib = L.load()
+    Bq, S, Cq = q.shape
+    Sk = Sk if Sk is not None else k.shape[1]
+    Dh = Cq // heads
+    if passes is None:
+        passes = [[AttnEntrySpec(b, b) for b in range(Bq)]]
+    Bo = Bo if Bo is not None else len(passes[0])
+    if out is None:
+        out = torch.empty(Bo, S, Cq, dtype=q.dtype, device=q.device)
+    d = L.AttnDesc()
+    d.q, d.k, d.vt, d.out, d.w_dev = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), _p(w_dev)
+    d.Bo, d.S, d.Sk, d.heads, d.D = Bo, S, Sk, heads, Dh
+    d.ldq, d.ldk, d.ldvt, d.ldo = Cq, k.shape[2], vt.shape[2], Cq
+    d.scale, d.npass = scale, len(passes)
+    for p, rows in enumerate(passes):
+        assert len(rows) == Bo
+        for b, sp in enumerate(rows):
+            e = d.e[p * L.ATT_MAXB + b]
+            if sp is None:
+                e.w_const = e.w_slope = 0.0
+                continue
+            e.q_row, e.kv_row, e.w_const, e.w_slope = sp.q_row, sp.kv_row, sp.w_const, sp.w_slope
+            e.wq, e.kmask, e.qsel, e.flags = _p(sp.wq), _p(sp.kmask), _p(sp.qsel), sp.flags
+    L.check(lib.ffn_attn(_stream(), _dt(q), C.byref(d)), "ffn_attn")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# norms
+# ---------------------------------------------------------------------------------------------------------------
+def gn_workspace(B, HW, C, device):
+    lib = L.load()
+    nchunk = lib.ffn_gn_nchunk(HW)
+    return (torch.empty(B * nchunk * 2 * C, dtype=torch.float32, device=device),
+            torch.empty(B, C, dtype=torch.float32, device=device), torch.empty(B, C, dtype=torch.float32, device=device))
+
+
+def groupnorm(x, gamma, beta, G, eps, silu=False, out=None, ws=None):
+    """x: [B, HW, C]."""
+    lib = L.load()
+    B, HW, Cc = x.shape
+    if ws is None:
+        ws = gn_workspace(B, HW, Cc, x.device)
+    partial, scale, shift = ws
+    L.check(lib.ffn_gn_stats(_stream(), _dt(x), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B, HW, Cc, G, eps,
+                             partial.data_ptr(), scale.data_ptr(), shift.data_ptr()), "ffn_gn_stats")
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(lib.ffn_gn_apply(_stream(), _dt(x), x.data_ptr(), out.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, HW, Cc,
+                             1 if silu else 0), "ffn_gn_apply")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    lib = L.load()
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(lib.ffn_layernorm(_stream(), _dt(x), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, Cc, eps),
+            "ffn_layernorm")
+    return out
+
+
+def softmax_rows(x, scale=1.0, out=None):
+    lib = L.load()
+    N = x.shape[-1]
+    M = x.numel() // N
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(lib.ffn_softmax_rows(_stream(), _dt(x), x.data_ptr(), out.data_ptr(), M, N, scale), "ffn_softmax_rows")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# scheduler / guidance (fp32 NCHW, like the reference)
+# ---------------------------------------------------------------------------------------------------------------
+def cfg_masked(eps_u, eps_c, mask_f, cfg, out=None):
+    lib = L.load()
+    if out is None:
+        out = torch.empty_like(eps_u)
+    HW = eps_u.shape[-1] * eps_u.shape[-2]
+    L.check(lib.ffn_cfg_masked(_stream(), eps_u.data_ptr(), eps_c.data_ptr(), _p(mask_f), float(cfg), out.data_ptr(),
+                               eps_u.numel(), HW), "ffn_cfg_masked")
+    return out
+
+
+def ddim_inv_step(eps, x, c_bt, c_at, c_an, c_bn, want_pred_x0=False):
+    lib = L.load()
+    x_next = torch.empty_like(x)
+    p0 = torch.empty_like(x) if want_pred_x0 else None
+    L.check(lib.ffn_ddim_inv_step(_stream(), eps.data_ptr(), x.data_ptr(), c_bt, c_at, c_an, c_bn, x_next.data_ptr(), _p(p0),
+                                  x.numel()), "ffn_ddim_inv_step")
+    return x_next, p0
+
+
+def ddim_ctrl_step(eps, x, noise, m_f, om_f, c_bt, c_at, c_ap, c_dir, c_dirm, stdv, row_masked, want_pred_x0=False):
+    lib = L.load()
+    rows = x.shape[0]
+    d = L.CtrlStepDesc()
+    x_prev = torch.empty_like(x)
+    p0 = torch.empty_like(x) if want_pred_x0 else None
+    d.eps, d.x, d.noise, d.m, d.om = eps.data_ptr(), x.data_ptr(), _p(noise), m_f.data_ptr(), om_f.data_ptr()
+    d.x_prev, d.pred_x0 = x_prev.data_ptr(), _p(p0)
+    d.c_bt, d.c_at, d.c_ap, d.c_dir = c_bt, c_at, c_ap, c_dir
+    for b in range(rows):
+        d.c_dirm[b], d.stdv[b], d.row_masked[b] = c_dirm[b], stdv[b], int(row_masked[b])
+    d.rows, d.CHW, d.HW = rows, x[0].numel(), x.shape[-1] * x.shape[-2]
+    L.check(lib.ffn_ddim_ctrl_step(_stream(), C.byref(d)), "ffn_ddim_ctrl_step")
+    return x_prev, p0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# layout / misc
+# ---------------------------------------------------------------------------------------------------------------
+def pack_nchw(src, src_rows, CP, dtype, out=None):
+    """fp32 NCHW [Bs,Cl,H,W] -> dtype NHWC [len(src_rows), HW, CP]."""
+    lib = L.load()
+    Bs, Cl, H, W = src.shape
+    B = len(src_rows)
+    if out is None:
+        out = torch.empty(B, H * W, CP, dtype=dtype, device=src.device)
+    d = L.PackDesc()
+    d.src, d.dst = src.data_ptr(), out.data_ptr()
+    for i, r in enumerate(src_rows):
+        d.src_row[i] = r
+    d.B, d.Cl, d.CP, d.HW = B, Cl, CP, H * W
+    L.check(lib.ffn_pack_nchw(_stream(), _dt(out), C.byref(d)), "ffn_pack_nchw")
+    return out
+
+
+def nhwc_to_nchw_f32(src, C_, H, W, out=None):
+    lib = L.load()
+    B, HW, ld = src.shape
+    if out is None:
+        out = torch.empty(B, C_, H, W, dtype=torch.float32, device=src.device)
+    L.check(lib.ffn_nhwc_to_nchw_f32(_stream(), src.data_ptr(), out.data_ptr(), B, HW, C_, ld), "ffn_nhwc_to_nchw_f32")
+    return out
+
+
+def concat(a, b, out=None):
+    lib = L.load()
+    C1, C2 = a.shape[-1], b.shape[-1]
+    rows = a.numel() // C1
+    if out is None:
+        out = torch.empty(*a.shape[:-1], C1 + C2, dtype=a.dtype, device=a.device)
+    L.check(lib.ffn_concat(_stream(), _dt(a), a.data_ptr(), b.data_ptr(), out.data_ptr(), rows, C1, C2), "ffn_concat")
+    return out
+
+
+def timestep_freqs(dim, device, max_period=10000.0, shift=0.0):
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32) / (half - shift)
+    return torch.exp(exponent).to(device)
+
+
+def timestep_embed(t_dev, freq, B, dtype, flip=True, out=None):
+    lib = L.load()
+    half = freq.numel()
+    if out is None:
+        out = torch.empty(B, 2 * half, dtype=dtype, device=freq.device)
+    L.check(lib.ffn_timestep_embed(_stream(), _dt(out), t_dev.data_ptr(), freq.data_ptr(), out.data_ptr(), B, half,
+                                   1 if flip else 0), "ffn_timestep_embed")
+    return out
+
+
+def transpose(src, ld_dst=None, out=None):
+    """[B,R,C] -> [B,C,ld_dst] (first R columns written)."""
+    lib = L.load()
+    B, R, Cc = src.shape
+    ld_dst = ld_dst or R
+    if out is None:
+        out = torch.zeros(B, Cc, ld_dst, dtype=src.dtype, device=src.device)
+    L.check(lib.ffn_transpose(_stream(), _dt(src), src.data_ptr(), out.data_ptr(), B, R, Cc, Cc, ld_dst), "ffn_transpose")
+    return out
+
+
+def cast(src, dtype, out=None):
+    lib = L.load()
+    if out is None:
+        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    L.check(lib.ffn_cast(_stream(), _dt(src), _dt(out), src.data_ptr(), out.data_ptr(), src.numel()), "ffn_cast")
+    return out
+
+
+def image_to_nhwc(img_u8, CP, dtype, out=None):
+    """uint8 [B,H,W,3] -> dtype [B,HW,CP] in [-1,1]."""
+    lib = L.load()
+    B, H, W, _ = img_u8.shape
+    if out is None:
+        out = torch.empty(B, H * W, CP, dtype=dtype, device=img_u8.device)
+    L.check(lib.ffn_image_to_nhwc(_stream(), _dt(out), img_u8.data_ptr(), out.data_ptr(), B * H * W, CP), "ffn_image_to_nhwc")
+    return out
+
+
+def nhwc_to_image(src, H, W, out=None):
+    lib = L.load()
+    B, HW, ld = src.shape
+    if out is None:
+        out = torch.empty(B, 3, H, W, dtype=torch.float32, device=src.device)
+    L.check(lib.ffn_nhwc_to_image(_stream(), _dt(src), src.data_ptr(), out.data_ptr(), B, HW, ld), "ffn_nhwc_to_image")
+    return out

@@ -1,0 +1,150 @@
+/* freefine_hip.h -- C ABI of libfreefine_hip.so: the MI355X (gfx950) kernels behind the FreeFine
+ * DDIM-inversion + guided-denoising hot path.
+ *
+ * The reference (CIawevy/FreeFine) has no FFI of its own: its "operator API" for this path is Python that
+ * monkey-patches diffusers (src/utils/attention.py:226-564) and calls torch ops.  Each entry point below names
+ * the reference code it replaces (paths relative to /root/reference).  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. the torch caching allocator); the library never
+ *     allocates, frees or retains memory; scratch is passed in explicitly;
+ *   - every call enqueues on the hipStream_t given as `stream` (void* so the header needs no HIP include), is
+ *     asynchronous with respect to the host and performs no synchronisation -> capturable in a hipGraph;
+ *   - return value 0 = success, negative = error (FFN_E*); ffn_last_error() returns a thread-local message;
+ *   - dtype selects the element type of activations / weights: FFN_F32 (exact fp32 MFMA, "parity mode") or
+ *     FFN_BF16 (bf16 MFMA operands, fp32 accumulation, "fast mode").  Norm parameters, biases, masks-as-weights,
+ *     latents and scheduler tensors are always fp32;
+ *   - activations are channel-contiguous: [batch, H*W, C].
+ */
+#ifndef FREEFINE_HIP_H
+#define FREEFINE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { FFN_F32 = 0, FFN_BF16 = 1 };
+enum { FFN_OK = 0, FFN_EINVAL = -22, FFN_ENOSYS = -38, FFN_EHIP = -5 };
+
+int ffn_version(void);
+const char* ffn_last_error(void);
+/* fills name (<=64 bytes) with the gcnArchName of `device`, returns CU count or negative error. */
+int ffn_device_info(int device, char* name, int name_len);
+
+/* ---- implicit GEMM: Linear / 1x1 conv (dense A) and 3x3 conv (im2col gather) ------------------------------
+ * out[m,n] = epi( alpha * sum_k A(m,k) W[n,k] ), W is [N][Kpad] (K contiguous, zero padded to Kpad, Kpad % kstage == 0
+ * with kstage = 32 (f32) / 64 (bf16)).
+ * Replaces: diffusers ResnetBlock2D/Downsample2D/Upsample2D/Linear modules reached from override_forward
+ * (src/utils/attention.py:105-214) and to_q/to_k/to_v/to_out in the hooked Attention.forward (attention.py:372-407). */
+enum {
+    FFN_IG_OUT_SILU = 1 << 0,
+    FFN_IG_OUT_F32 = 1 << 1,
+    FFN_IG_GEGLU = 1 << 2,         /* N = 2*Nout; 16-column blocks alternate hidden/gate; out = hidden * gelu(gate) */
+    FFN_IG_OUT_TRANSPOSED = 1 << 3 /* out[b][n][s], row stride ldo, m = b*rows_per_batch + s (V^T for ffn_attn) */
+};
+typedef struct ffn_igemm_desc {
+    const void* A;        /* dense: [M][lda];  conv: NHWC input [B][Hin][Win][Cin] */
+    const void* W;        /* [N][Kpad] */
+    void* out;            /* [M][ldo] (or transposed) */
+    const float* bias;    /* [N] or NULL (GEGLU: packed like W rows) */
+    const float* rowbias; /* [batch][ldrb] or NULL; batch = m / rows_per_batch (time-embedding projection) */
+    const void* residual; /* [M][ldr] or NULL */
+    int M, N, K, Kpad;
+    int lda, ldo, ldr, ldrb;
+    int rows_per_batch;
+    int Hin, Win, Cin, Hout, Wout, stride, pad, upsample; /* conv only; upsample=1 fuses nearest-2x of the input */
+    int flags;
+    float alpha;
+    int conv; /* 0 = dense, 1 = 3x3 conv */
+} ffn_igemm_desc;
+int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
+
+/* ---- multi-pass masked attention (the FreeFine attention modulation) -----------------------------------------
+ * out[b,q,h,:] = sum_p w_p(b) * wq_p[q] * softmax_k(scale*<Q[qrow_p(b),q,h],K[kvrow_p(b),k,h]> + mask_p(q,k)) V[kvrow_p(b),k,h]
+ * Replaces: Attention_Modulator.Temporal_contextal_attention{,_bg,_compose}, modulate_local_cross_attn{,_bg,_compose},
+ * style_align_share_attention, mask_attention, get_attention_scores, get_cross_hidden_state and the prepare_*_mask
+ * builders (src/utils/attention.py:774-1432) plus the plain branch of ca_forward (attention.py:394-404). */
+#define FFN_ATT_MAXP 4
+#define FFN_ATT_MAXB 8
+enum { FFN_ATT_HEAD_RULE = 1, FFN_ATT_UNIFORM_SEL1 = 2, FFN_ATT_UNIFORM_SEL0 = 4 };
+typedef struct ffn_attn_entry {
+    int q_row, kv_row;      /* batch rows supplying Q and K/V for this (pass, output row) */
+    float w_const, w_slope; /* weight = w_const + w_slope * (*w_dev); both 0 -> entry skipped */
+    const float* wq;        /* per-query weight [S] or NULL */
+    const uint8_t* kmask;   /* per-key byte mask [Sk] or NULL */
+    const uint8_t* qsel;    /* per-query selector [S] or NULL (=1): allowed(q,k) = (kmask[k]!=0) == (qsel[q]!=0) */
+    int flags;              /* FFN_ATT_HEAD_RULE: mask applies only where (b*heads+head) is even (attention.py:859 vs 761);
+                               FFN_ATT_UNIFORM_SEL1/0: the allowed set for sel=1/0 is empty -> uniform over all keys */
+    int pad_;
+} ffn_attn_entry;
+typedef struct ffn_attn_desc {
+    const void* q;      /* [Bq][S][ldq], head h at column h*D */
+    const void* k;      /* [Bk][Sk][ldk] */
+    const void* vt;     /* [Bk][heads*D][ldvt]  V transposed (ldvt >= Sk, multiple of 8, padding finite) */
+    void* out;          /* [Bo][S][ldo] */
+    const float* w_dev; /* device scalar (context_guidance) or NULL */
+    int Bo, S, Sk, heads, D;
+    int ldq, ldk, ldvt, ldo;
+    float scale;
+    int npass;
+    ffn_attn_entry e[FFN_ATT_MAXP * FFN_ATT_MAXB]; /* entry (p,b) at p*FFN_ATT_MAXB + b */
+} ffn_attn_desc;
+int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d);
+
+/* ---- normalisation ------------------------------------------------------------------------------------------- */
+/* GroupNorm statistics -> per-(batch,channel) scale/shift (fp32).  partial_ws: >= B*nchunk*2*C floats where
+ * nchunk = ffn_gn_nchunk(HW).  Replaces torch GroupNorm inside diffusers blocks (attention.py:105-214). */
+int ffn_gn_nchunk(int HW);
+int ffn_gn_stats(void* stream, int dtype, const void* x, const float* gamma, const float* beta, int B, int HW, int C, int G,
+                 float eps, float* partial_ws, float* scale, float* shift);
+int ffn_gn_apply(void* stream, int dtype, const void* x, void* y, const float* scale, const float* shift, int B, int HW,
+                 int C, int silu);
+int ffn_layernorm(void* stream, int dtype, const void* x, void* y, const float* gamma, const float* beta, int M, int C,
+                  float eps);
+int ffn_softmax_rows(void* stream, int dtype, const void* x, void* y, long M, int N, float scale);
+
+/* ---- scheduler / guidance elementwise (fp32, NCHW like the reference) ------------------------------------------ */
+/* eps = eu + cfg*(ec-eu)*mask   (src/demo/model.py:605-611; mask NULL -> :608) */
+int ffn_cfg_masked(void* stream, const float* eps_u, const float* eps_c, const float* mask, float cfg, float* eps, long n,
+                   int HW);
+/* inv_step (src/demo/model.py:109-132); coefficients are the fp32 values torch computes: c_bt=sqrt(1-a_t),
+ * c_at=sqrt(a_t), c_an=sqrt(a_next), c_bn=sqrt(1-a_next) */
+int ffn_ddim_inv_step(void* stream, const float* eps, const float* x, float c_bt, float c_at, float c_an, float c_bn,
+                      float* x_next, float* pred_x0, long n);
+/* ctrl_step (src/demo/model.py:134-198) */
+typedef struct ffn_ctrl_step_desc {
+    const float* eps;
+    const float* x;
+    const float* noise; /* NULL when eta == 0 */
+    const float* m;     /* float(mask) [HW] */
+    const float* om;    /* float(1 - mask) evaluated in the mask's own dtype (uint8 wrap kept) [HW] */
+    float* x_prev;
+    float* pred_x0; /* may be NULL */
+    float c_bt, c_at, c_ap, c_dir;
+    float c_dirm[8], stdv[8];
+    int row_masked[8];
+    int rows, CHW, HW;
+} ffn_ctrl_step_desc;
+int ffn_ddim_ctrl_step(void* stream, const ffn_ctrl_step_desc* d);
+
+/* ---- layout / misc ----------------------------------------------------------------------------------------------- */
+typedef struct ffn_pack_desc {
+    const float* src; /* fp32 NCHW [Bsrc][Cl][HW] */
+    void* dst;        /* T NHWC [B][HW][CP], channels >= Cl zero */
+    int src_row[16];
+    int B, Cl, CP, HW;
+} ffn_pack_desc;
+int ffn_pack_nchw(void* stream, int dtype, const ffn_pack_desc* d);
+int ffn_nhwc_to_nchw_f32(void* stream, const float* src, float* dst, int B, int HW, int C, int ld);
+int ffn_concat(void* stream, int dtype, const void* a, const void* b, void* out, long rows, int C1, int C2);
+int ffn_timestep_embed(void* stream, int dtype, const float* t_dev, const float* freq, void* out, int B, int half, int flip);
+int ffn_transpose(void* stream, int dtype, const void* src, void* dst, int B, int R, int C, int ld_src, int ld_dst);
+int ffn_cast(void* stream, int src_dtype, int dst_dtype, const void* src, void* dst, long n);
+int ffn_image_to_nhwc(void* stream, int dtype, const uint8_t* img, void* dst, long npix, int CP);
+int ffn_nhwc_to_image(void* stream, int dtype, const void* src, float* dst, int B, int HW, int ld);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

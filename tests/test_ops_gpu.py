@@ -1,0 +1,321 @@
+"""Per-kernel numerics: every HIP kernel (called through the C ABI) against a plain torch fp32/fp64 statement of the
+same op on identical seeded inputs.  Tolerances: fp32 mode <= 2e-5 of the output scale (exact-fp32 MFMA, different
+summation order only); bf16 mode compares against the same op evaluated on bf16-rounded inputs, <= 1.5e-2."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 1.5e-2
+
+
+def rnd(shape, dtype, dev, g, scale=1.0):
+    x = (torch.randn(*shape, generator=g) * scale).to(dtype)
+    return x.to(dev)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(256, 320, 320), (4096, 1280, 320), (77 * 4, 640, 1024), (4, 1280, 320),
+                                    (1000, 4, 320), (16384, 320, 1280), (130, 200, 72)])
+def test_linear(gpu, dtype, M, N, K):
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    K = K // ops.epc(dtype) * ops.epc(dtype)
+    x = rnd((M, K), dtype, gpu, g)
+    w = rnd((N, K), dtype, gpu, g, K ** -0.5)
+    b = torch.randn(N, generator=g).to(gpu)
+    res = rnd((M, N), dtype, gpu, g)
+    wp = ops.pack_linear(w, dtype)
+    ref = x.double() @ w.double().t() + b.double()
+    out = ops.linear(x, wp, b, K=K)
+    assert relerr(out, ref) < tol(dtype)
+    out = ops.linear(x, wp, b, K=K, residual=res)
+    assert relerr(out, ref + res.double()) < tol(dtype)
+    out = ops.linear(x, wp, b, K=K, silu=True)
+    assert relerr(out, F.silu(ref)) < tol(dtype)
+    out = ops.linear(x, wp, None, K=K, out_f32=True)
+    assert out.dtype == torch.float32
+    assert relerr(out, ref - b.double()) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_rowbias_and_geglu(gpu, dtype):
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, S, K, Fh = 2, 192, 320, 1280
+    x = rnd((B, S, K), dtype, gpu, g)
+    w = rnd((2 * Fh, K), dtype, gpu, g, K ** -0.5)
+    b = torch.randn(2 * Fh, generator=g).to(gpu)
+    wp, bp = ops.pack_geglu(w, b, dtype)
+    out = ops.linear(x, wp, bp, geglu=True)
+    y = x.double() @ w.double().t() + b.double()
+    ref = y[..., :Fh] * F.gelu(y[..., Fh:])
+    assert out.shape == (B, S, Fh)
+    assert relerr(out, ref) < tol(dtype)
+    # row bias (time-embedding projection added per batch row)
+    w2 = rnd((640, K), dtype, gpu, g, K ** -0.5)
+    rb = torch.randn(B, 640, generator=g).to(gpu)
+    out = ops.linear(x, ops.pack_linear(w2, dtype), None, rowbias=rb, rows_per_batch=S)
+    ref = x.double() @ w2.double().t() + rb.double()[:, None, :]
+    assert relerr(out, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S", [256, 77])
+def test_linear_transposed(gpu, dtype, S):
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, K, N = 3, 320, 320
+    x = rnd((B, S, K), dtype, gpu, g)
+    w = rnd((N, K), dtype, gpu, g, K ** -0.5)
+    ld = (S + 7) // 8 * 8
+    out = ops.linear(x, ops.pack_linear(w, dtype), None, rows_per_batch=S, transposed_ld=ld)
+    ref = (x.double() @ w.double().t()).transpose(1, 2)
+    assert out.shape == (B, N, ld)
+    assert relerr(out[:, :, :S], ref) < tol(dtype)
+    assert (out[:, :, S:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, H=16, W=16, Cin=64, Cout=96, stride=1, pad=1, up=False),
+    dict(B=2, H=16, W=16, Cin=64, Cout=64, stride=2, pad=1, up=False),
+    dict(B=1, H=8, W=8, Cin=128, Cout=64, stride=1, pad=1, up=True),
+    dict(B=4, H=8, W=8, Cin=320, Cout=4, stride=1, pad=1, up=False),
+    dict(B=2, H=12, W=20, Cin=8, Cout=320, stride=1, pad=1, up=False),
+    dict(B=1, H=16, W=16, Cin=32, Cout=32, stride=2, pad=0, up=False),  # VAE encoder: pad (0,1,0,1) then stride 2
+])
+def test_conv3x3(gpu, dtype, cfg):
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, H, W, Cin, Cout = cfg["B"], cfg["H"], cfg["W"], cfg["Cin"], cfg["Cout"]
+    x = rnd((B, Cin, H, W), dtype, gpu, g)
+    w = rnd((Cout, Cin, 3, 3), dtype, gpu, g, (9 * Cin) ** -0.5)
+    b = torch.randn(Cout, generator=g).to(gpu)
+    xin = x.double()
+    if cfg["up"]:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    if cfg["pad"] == 0:
+        xin = F.pad(xin, (0, 1, 0, 1))
+        ref = F.conv2d(xin, w.double(), b.double(), stride=cfg["stride"], padding=0)
+    else:
+        ref = F.conv2d(xin, w.double(), b.double(), stride=cfg["stride"], padding=1)
+    Ho, Wo = ref.shape[-2:]
+    x_nhwc = x.permute(0, 2, 3, 1).reshape(B, H * W, Cin).contiguous()
+    out = ops.conv3x3(x_nhwc, ops.pack_conv3x3(w, dtype), b, B, H, W, Cin, stride=cfg["stride"], pad=cfg["pad"],
+                      upsample=cfg["up"], Hout=Ho, Wout=Wo)
+    ref_nhwc = ref.permute(0, 2, 3, 1).reshape(B, Ho * Wo, Cout)
+    assert relerr(out, ref_nhwc) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_epilogue(gpu, dtype):
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(12)
+    B, H, W, Cin, Cout = 2, 16, 16, 64, 128
+    x = rnd((B, H * W, Cin), dtype, gpu, g)
+    w = rnd((Cout, Cin, 3, 3), dtype, gpu, g, (9 * Cin) ** -0.5)
+    b = torch.randn(Cout, generator=g).to(gpu)
+    rb = torch.randn(B, Cout, generator=g).to(gpu)
+    res = rnd((B, H * W, Cout), dtype, gpu, g)
+    ref = F.conv2d(x.double().reshape(B, H, W, Cin).permute(0, 3, 1, 2), w.double(), b.double(), padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(B, H * W, Cout) + rb.double()[:, None] + res.double()
+    out = ops.conv3x3(x, ops.pack_conv3x3(w, dtype), b, B, H, W, Cin, rowbias=rb, residual=res)
+    assert relerr(out, ref) < tol(dtype)
+
+
+def ref_attention(q, k, v, heads, scale, allowed=None):
+    """q [S,C], k,v [Sk,C] double; allowed [heads,S,Sk] bool or None.  Empty rows -> uniform (reference behaviour)."""
+    S, Cc = q.shape
+    d = Cc // heads
+    out = torch.zeros(S, Cc, dtype=torch.float64)
+    for h in range(heads):
+        sl = slice(h * d, (h + 1) * d)
+        s = scale * q[:, sl] @ k[:, sl].t()
+        if allowed is not None:
+            a = allowed[h]
+            s = torch.where(a, s, torch.full_like(s, -1e300))
+            empty = ~a.any(dim=1)
+            s[empty] = 0.0
+        out[:, sl] = torch.softmax(s, dim=-1) @ v[:, sl]
+    return out
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S,Sk,heads,D", [(256, 256, 5, 64), (64, 77, 8, 40), (200, 130, 2, 80), (128, 64, 2, 160)])
+def test_attention_plain(gpu, dtype, S, Sk, heads, D):
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(S + D)
+    B, Cc = 2, heads * D
+    q = rnd((B, S, Cc), dtype, gpu, g)
+    k = rnd((B, Sk, Cc), dtype, gpu, g)
+    v = rnd((B, Sk, Cc), dtype, gpu, g)
+    vt = ops.transpose(v, ld_dst=(Sk + 7) // 8 * 8)
+    scale = D ** -0.5
+    out = ops.attention(q, k, vt, heads, scale, Sk=Sk)
+    for b in range(B):
+        ref = ref_attention(q[b].double().cpu(), k[b].double().cpu(), v[b].double().cpu(), heads, scale)
+        assert relerr(out[b], ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_tca_edit(gpu, dtype):
+    """TCA edit branch: K/V from the reference rows, per-key source mask, per-query selector, tiled-head rule,
+    context-guidance blend with the self pass (weights from a device scalar)."""
+    from freefine_amd import ops
+    from freefine_amd._lib import ATT_HEAD_RULE
+    g = torch.Generator().manual_seed(21)
+    B, S, heads, D = 4, 192, 5, 64
+    Cc = heads * D
+    q = rnd((B, S, Cc), dtype, gpu, g)
+    k = rnd((B, S, Cc), dtype, gpu, g)
+    v = rnd((B, S, Cc), dtype, gpu, g)
+    vt = ops.transpose(v)
+    src = (torch.rand(S, generator=g) > 0.6).to(torch.uint8)
+    tgt = (torch.rand(S, generator=g) > 0.5).to(torch.uint8)
+    cg = 0.35
+    cg_dev = torch.tensor([cg], dtype=torch.float32, device=gpu)
+    scale = D ** -0.5
+    ref_rows = [1, 1, 3, 3]
+    p_ref = [ops.AttnEntrySpec(b, ref_rows[b], 0.0, 1.0, kmask=src.to(gpu), qsel=tgt.to(gpu), flags=ATT_HEAD_RULE) for b in range(B)]
+    p_self = [ops.AttnEntrySpec(b, b, 1.0, -1.0) for b in range(B)]
+    out = ops.attention(q, k, vt, heads, scale, [p_ref, p_self], w_dev=cg_dev)
+    qc, kc, vc = q.double().cpu(), k.double().cpu(), v.double().cpu()
+    for b in range(B):
+        allowed = torch.ones(heads, S, S, dtype=torch.bool)
+        for h in range(heads):
+            if (b * heads + h) % 2 == 0:
+                allowed[h] = (src[None, :] != 0) == (tgt[:, None] != 0)
+        r = ref_attention(qc[b], kc[ref_rows[b]], vc[ref_rows[b]], heads, scale, allowed)
+        s = ref_attention(qc[b], kc[b], vc[b], heads, scale)
+        assert relerr(out[b], cg * r + (1 - cg) * s) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_uniform_and_wq(gpu, dtype):
+    """empty allowed set -> uniform softmax over all keys; per-query weights; skipped entries; q_row remap."""
+    from freefine_amd import ops
+    from freefine_amd._lib import ATT_UNIFORM_SEL1
+    g = torch.Generator().manual_seed(22)
+    B, S, Sk, heads, D = 3, 100, 77, 8, 40
+    Cc = heads * D
+    q = rnd((B, S, Cc), dtype, gpu, g)
+    k = rnd((B, Sk, Cc), dtype, gpu, g)
+    v = rnd((B, Sk, Cc), dtype, gpu, g)
+    vt = ops.transpose(v, ld_dst=80)
+    scale = D ** -0.5
+    km = torch.zeros(Sk, dtype=torch.uint8, device=gpu)  # no key has mask==1 -> sel=1 queries see a uniform softmax
+    wq = torch.rand(S, generator=g).to(gpu)
+    p0 = [ops.AttnEntrySpec(0, 0, 1.0, 0.0, kmask=km, flags=ATT_UNIFORM_SEL1), ops.AttnEntrySpec(1, 1), ops.AttnEntrySpec(2, 2, wq=wq)]
+    p1 = [None, None, ops.AttnEntrySpec(0, 1, 0.5)]
+    out = ops.attention(q, k, vt, heads, scale, [p0, p1], Sk=Sk)
+    qc, kc, vc = q.double().cpu(), k.double().cpu(), v.double().cpu()
+    ref0 = vc[0].mean(dim=0, keepdim=True).expand(S, Cc)
+    assert relerr(out[0], ref0) < tol(dtype)
+    assert relerr(out[1], ref_attention(qc[1], kc[1], vc[1], heads, scale)) < tol(dtype)
+    ref2 = wq.double().cpu()[:, None] * ref_attention(qc[2], kc[2], vc[2], heads, scale) + 0.5 * ref_attention(qc[0], kc[1], vc[1], heads, scale)
+    assert relerr(out[2], ref2) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,HW,Cc", [(2, 256, 320), (1, 64, 1280), (2, 1024, 960), (1, 4096, 128), (2, 64, 2560)])
+def test_groupnorm(gpu, dtype, B, HW, Cc):
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(HW + Cc)
+    x = rnd((B, HW, Cc), dtype, gpu, g, 2.0) + 0.5
+    gamma = torch.randn(Cc, generator=g).to(gpu)
+    beta = torch.randn(Cc, generator=g).to(gpu)
+    for silu in (False, True):
+        out = ops.groupnorm(x, gamma, beta, 32, 1e-5, silu=silu)
+        ref = F.group_norm(x.double().transpose(1, 2), 32, gamma.double(), beta.double(), 1e-5).transpose(1, 2)
+        if silu:
+            ref = F.silu(ref)
+        assert relerr(out, ref) < (1e-5 if dtype == torch.float32 else 1.5e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Cc", [(300, 320), (77, 1024), (64, 1280), (10, 640)])
+def test_layernorm(gpu, dtype, M, Cc):
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(M + Cc)
+    x = rnd((M, Cc), dtype, gpu, g, 3.0) + 1.0
+    gamma = torch.randn(Cc, generator=g).to(gpu)
+    beta = torch.randn(Cc, generator=g).to(gpu)
+    out = ops.layernorm(x, gamma, beta, 1e-5)
+    ref = F.layer_norm(x.double(), (Cc,), gamma.double(), beta.double(), 1e-5)
+    assert relerr(out, ref) < (1e-5 if dtype == torch.float32 else 1.5e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_softmax_concat_transpose_cast(gpu, dtype):
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = rnd((50, 1000), dtype, gpu, g, 3.0)
+    assert relerr(ops.softmax_rows(x, 0.7), torch.softmax(x.double() * 0.7, -1)) < tol(dtype)
+    a, b = rnd((3, 70, 64), dtype, gpu, g), rnd((3, 70, 128), dtype, gpu, g)
+    assert torch.equal(ops.concat(a, b), torch.cat([a, b], -1))
+    t = ops.transpose(a, ld_dst=72)
+    assert torch.equal(t[:, :, :70], a.transpose(1, 2))
+    other = torch.bfloat16 if dtype == torch.float32 else torch.float32
+    assert torch.equal(ops.cast(a, other), a.to(other))
+
+
+def test_scheduler_elementwise(gpu):
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(9)
+    eu, ec = torch.randn(2, 4, 64, 64, generator=g).to(gpu), torch.randn(2, 4, 64, 64, generator=g).to(gpu)
+    mask = (torch.rand(64, 64, generator=g) > 0.5).float().to(gpu)
+    out = ops.cfg_masked(eu, ec, mask.reshape(-1), 7.5)
+    ref = eu + 7.5 * (ec - eu) * mask
+    assert relerr(out, ref) < 1e-6
+    out = ops.cfg_masked(eu, ec, None, 7.5)
+    assert relerr(out, eu + 7.5 * (ec - eu)) < 1e-6
+    x = torch.randn(2, 4, 64, 64, generator=g).to(gpu)
+    xn, p0 = ops.ddim_inv_step(eu, x, 0.3, 0.95, 0.9, 0.43, want_pred_x0=True)
+    rp0 = (x - 0.3 * eu) / 0.95
+    assert relerr(p0, rp0) < 1e-6 and relerr(xn, 0.9 * rp0 + 0.43 * eu) < 1e-6
+    noise = torch.randn(2, 4, 64, 64, generator=g).to(gpu)
+    m = mask.reshape(-1)
+    om = (1 - mask).reshape(-1) * 255.0  # stands in for the uint8 wrap values: the kernel must use om as given
+    xp, _ = ops.ddim_ctrl_step(eu, x, noise, m, om, 0.3, 0.95, 0.97, 0.24, [0.2, 0.24], [0.13, 0.0], [1, 0])
+    rp0 = (x - 0.3 * eu) / 0.95
+    mm = torch.stack([mask, torch.ones_like(mask)])[:, None]
+    oo = torch.stack([(1 - mask) * 255.0, torch.zeros_like(mask)])[:, None]
+    cd = torch.tensor([0.2, 0.24], device=gpu)[:, None, None, None]
+    sd = torch.tensor([0.13, 0.0], device=gpu)[:, None, None, None]
+    ref = 0.97 * rp0 + (0.24 * eu * oo + cd * eu * mm) + sd * noise * mm
+    assert relerr(xp, ref) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pack_unpack_temb(gpu, dtype):
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(2)
+    lat = torch.randn(2, 4, 16, 16, generator=g).to(gpu)
+    p = ops.pack_nchw(lat, [0, 1, 0, 1], 8, dtype)
+    ref = torch.cat([lat, lat]).permute(0, 2, 3, 1).reshape(4, 256, 4)
+    assert relerr(p[..., :4], ref) < (1e-7 if dtype == torch.float32 else 5e-3)
+    assert (p[..., 4:] == 0).all()
+    e = torch.randn(3, 256, 4, generator=g).to(gpu)
+    assert torch.equal(ops.nhwc_to_nchw_f32(e, 4, 16, 16), e.permute(0, 2, 1).reshape(3, 4, 16, 16))
+    freq = ops.timestep_freqs(320, gpu)
+    t = torch.tensor([981.0], device=gpu)
+    emb = ops.timestep_embed(t, freq, 2, dtype)
+    arg = 981.0 * freq.double()
+    ref = torch.cat([arg.cos(), arg.sin()])[None].expand(2, -1)
+    assert relerr(emb, ref) < (2e-4 if dtype == torch.float32 else 1e-2)  # fp32 argument t*freq ~ 1e3 -> 6e-5 abs
+    img = torch.randint(0, 256, (1, 8, 8, 3), generator=g, dtype=torch.uint8).to(gpu)
+    x = ops.image_to_nhwc(img, 8, dtype)
+    assert relerr(x[..., :3], img.reshape(1, 64, 3).float() / 127.5 - 1) < (1e-6 if dtype == torch.float32 else 5e-3)
