@@ -2,7 +2,7 @@
 
 Activations are [B, HW, C] channel-contiguous tensors of dtype float32 ("parity mode") or bfloat16 ("fast mode").
 """
-import ctypes as C
+import ctypes as CT
 import math
 
 import torch
@@ -84,7 +84,7 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
     d.M, d.N, d.K, d.Kpad = M, N, K, w.shape[1]
     d.lda = x.shape[-1]
     d.rows_per_batch = rows_per_batch or M
-    d.ldrb = rowbias.shape[-1] if rowbias is not None else 0
+    d.ldrb = rowbias.stride(0) if rowbias is not None else 0
     flags = 0
     n_out = N
     if silu:
@@ -107,12 +107,12 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
     d.ldr = residual.shape[-1] if residual is not None else 0
     d.out = out.data_ptr()
     d.flags, d.alpha, d.conv = flags, alpha, 0
-    L.check(lib.ffn_igemm(_stream(), _dt(x), C.byref(d)), "ffn_igemm")
+    L.check(lib.ffn_igemm(_stream(), _dt(x), CT.byref(d)), "ffn_igemm")
     return out
 
 
 def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, out=None, residual=None, rowbias=None,
-            out_f32=False, Hout=None, Wout=None):
+            rowbias_ld=None, out_f32=False, Hout=None, Wout=None):
     """x: [B, Hin*Win, Cin] NHWC; w: packed [Cout, Kpad]; returns [B, Hout*Wout, Cout]."""
     lib = L.load()
     He, We = (Hin * 2, Win * 2) if upsample else (Hin, Win)
@@ -126,7 +126,7 @@ def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, ou
     d.M, d.N, d.K, d.Kpad = B * Hout * Wout, N, 9 * Cin, w.shape[1]
     d.lda = Cin
     d.rows_per_batch = Hout * Wout
-    d.ldrb = rowbias.shape[-1] if rowbias is not None else 0
+    d.ldrb = (rowbias_ld or rowbias.stride(0)) if rowbias is not None else 0
     if out is None:
         out = torch.empty(B, Hout * Wout, N, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     d.out, d.ldo = out.data_ptr(), N
@@ -134,7 +134,7 @@ def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, ou
     d.Hin, d.Win, d.Cin, d.Hout, d.Wout = Hin, Win, Cin, Hout, Wout
     d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
     d.flags, d.alpha, d.conv = (L.IG_OUT_F32 if out_f32 else 0), 1.0, 1
-    L.check(lib.ffn_igemm(_stream(), _dt(x), C.byref(d)), "ffn_igemm(conv)")
+    L.check(lib.ffn_igemm(_stream(), _dt(x), CT.byref(d)), "ffn_igemm(conv)")
     return out
 
 
@@ -150,11 +150,12 @@ class AttnEntrySpec:
         self.wq, self.kmask, self.qsel, self.flags = wq, kmask, qsel, flags
 
 
-def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=None, Bo=None):
+def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=None, Bo=None, C=None):
     """q: [Bq,S,C]; k: [Bk,Sk,C]; vt: [Bk,C,ldvt] (V transposed).  passes: list (per pass) of lists (per output
     row) of AttnEntrySpec or None (= skipped).  passes=None -> plain attention, row b uses its own K/V."""
     lib = L.load()
-    Bq, S, Cq = q.shape
+    Bq, S, _ = q.shape
+    Cq = C if C is not None else q.shape[2]          # q / k may be column views of a wider [B,S,ld] buffer
     Sk = Sk if Sk is not None else k.shape[1]
     Dh = Cq // heads
     if passes is None:
@@ -165,7 +166,7 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
     d = L.AttnDesc()
     d.q, d.k, d.vt, d.out, d.w_dev = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), _p(w_dev)
     d.Bo, d.S, d.Sk, d.heads, d.D = Bo, S, Sk, heads, Dh
-    d.ldq, d.ldk, d.ldvt, d.ldo = Cq, k.shape[2], vt.shape[2], Cq
+    d.ldq, d.ldk, d.ldvt, d.ldo = q.stride(1), k.stride(1), vt.stride(1), Cq
     d.scale, d.npass = scale, len(passes)
     for p, rows in enumerate(passes):
         assert len(rows) == Bo
@@ -176,7 +177,7 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
                 continue
             e.q_row, e.kv_row, e.w_const, e.w_slope = sp.q_row, sp.kv_row, sp.w_const, sp.w_slope
             e.wq, e.kmask, e.qsel, e.flags = _p(sp.wq), _p(sp.kmask), _p(sp.qsel), sp.flags
-    L.check(lib.ffn_attn(_stream(), _dt(q), C.byref(d)), "ffn_attn")
+    L.check(lib.ffn_attn(_stream(), _dt(q), CT.byref(d)), "ffn_attn")
     return out
 
 
@@ -261,7 +262,7 @@ def ddim_ctrl_step(eps, x, noise, m_f, om_f, c_bt, c_at, c_ap, c_dir, c_dirm, st
     for b in range(rows):
         d.c_dirm[b], d.stdv[b], d.row_masked[b] = c_dirm[b], stdv[b], int(row_masked[b])
     d.rows, d.CHW, d.HW = rows, x[0].numel(), x.shape[-1] * x.shape[-2]
-    L.check(lib.ffn_ddim_ctrl_step(_stream(), C.byref(d)), "ffn_ddim_ctrl_step")
+    L.check(lib.ffn_ddim_ctrl_step(_stream(), CT.byref(d)), "ffn_ddim_ctrl_step")
     return x_prev, p0
 
 
@@ -280,7 +281,7 @@ def pack_nchw(src, src_rows, CP, dtype, out=None):
     for i, r in enumerate(src_rows):
         d.src_row[i] = r
     d.B, d.Cl, d.CP, d.HW = B, Cl, CP, H * W
-    L.check(lib.ffn_pack_nchw(_stream(), _dt(out), C.byref(d)), "ffn_pack_nchw")
+    L.check(lib.ffn_pack_nchw(_stream(), _dt(out), CT.byref(d)), "ffn_pack_nchw")
     return out
 
 

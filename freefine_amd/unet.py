@@ -1,0 +1,306 @@
+"""SD UNet forward executed entirely by the HIP kernels of libfreefine_hip.so (no torch math on the path).
+
+Replaces: override_forward.forward (/root/reference/src/utils/attention.py:11-225) + the diffusers-0.18 blocks it
+drives + the hooked Attention.forward (attention.py:350-418), returning a bare [B,4,h,w] fp32 tensor like the reference.
+
+MI355X-first layout decisions
+  * activations are [B, H*W, C] (channel-contiguous) end to end: conv (implicit GEMM), GroupNorm, LayerNorm, attention and
+    the Linear layers all read/write the same buffers -- the NCHW<->NLC transposes of the reference do not exist;
+  * every weight is repacked once to [N][Kpad] (K contiguous); conv weights to (ky,kx,ci) order; GEGLU projections are
+    interleaved so hidden*gelu(gate) happens in the GEMM epilogue; the 22 time-embedding projections are one GEMM;
+  * V is produced transposed by its projection's epilogue, the layout the attention kernel's PV product wants;
+  * cross-attention K / V^T depend only on the text embeddings and are computed once per prompt set, not per step;
+  * per-step scalars (timestep, context_guidance) live in device memory, so a whole forward can be captured in a hipGraph
+    and replayed (capture=True) -- ~700 launches become one graph launch.
+"""
+import torch
+
+from . import ops
+from .config import UNetConfig
+
+
+class _Res:
+    pass
+
+
+class HipUNet:
+    def __init__(self, cfg: UNetConfig, state, dtype=torch.bfloat16, device="cuda:0"):
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self.in_channels = cfg.in_channels
+        self.hook, self.controller = "edit", None
+        self._graphs = {}
+        self._text_cache = None
+        self.use_graph = False
+        self._pack(state)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # weights
+    # ------------------------------------------------------------------------------------------------------------
+    def _f32(self, t):
+        return t.detach().float().contiguous().to(self.device)
+
+    def _lin(self, st, name, bias=True):
+        w = st[name + ".weight"].to(self.device)
+        if w.ndim == 4:
+            w = w.reshape(w.shape[0], w.shape[1])
+        return ops.pack_linear(w.float(), self.dtype), (self._f32(st[name + ".bias"]) if bias else None), w.shape[1]
+
+    def _conv(self, st, name, cin_pad=None):
+        w = st[name + ".weight"].to(self.device)
+        return ops.pack_conv3x3(w.float(), self.dtype, cin_pad), self._f32(st[name + ".bias"]), (cin_pad or w.shape[1])
+
+    def _resnet(self, st, p, temb_list):
+        r = _Res()
+        r.n1 = (self._f32(st[p + ".norm1.weight"]), self._f32(st[p + ".norm1.bias"]))
+        r.c1 = self._conv(st, p + ".conv1")
+        r.n2 = (self._f32(st[p + ".norm2.weight"]), self._f32(st[p + ".norm2.bias"]))
+        r.c2 = self._conv(st, p + ".conv2")
+        r.cout = st[p + ".conv1.weight"].shape[0]
+        r.sc = self._lin(st, p + ".conv_shortcut") if (p + ".conv_shortcut.weight") in st else None
+        r.temb_off = sum(w.shape[0] for w, _ in temb_list)
+        temb_list.append((st[p + ".time_emb_proj.weight"].float(), st[p + ".time_emb_proj.bias"].float()))
+        return r
+
+    def _transformer(self, st, p, heads):
+        t = _Res()
+        t.heads = heads
+        t.norm = (self._f32(st[p + ".norm.weight"]), self._f32(st[p + ".norm.bias"]))
+        t.proj_in = self._lin(st, p + ".proj_in")
+        t.proj_out = self._lin(st, p + ".proj_out")
+        b = p + ".transformer_blocks.0"
+        t.ln = [(self._f32(st[f"{b}.norm{i}.weight"]), self._f32(st[f"{b}.norm{i}.bias"])) for i in (1, 2, 3)]
+        wq, wk = st[f"{b}.attn1.to_q.weight"].float(), st[f"{b}.attn1.to_k.weight"].float()
+        t.C = wq.shape[0]
+        t.w_qk1 = ops.pack_linear(torch.cat([wq, wk], 0).to(self.device), self.dtype)          # self-attn Q|K in one GEMM
+        t.w_v1 = ops.pack_linear(st[f"{b}.attn1.to_v.weight"].float().to(self.device), self.dtype)
+        t.o1 = self._lin(st, f"{b}.attn1.to_out.0")
+        t.w_q2 = ops.pack_linear(st[f"{b}.attn2.to_q.weight"].float().to(self.device), self.dtype)
+        t.w_k2 = ops.pack_linear(st[f"{b}.attn2.to_k.weight"].float().to(self.device), self.dtype)
+        t.w_v2 = ops.pack_linear(st[f"{b}.attn2.to_v.weight"].float().to(self.device), self.dtype)
+        t.o2 = self._lin(st, f"{b}.attn2.to_out.0")
+        t.ff1 = ops.pack_geglu(st[f"{b}.ff.net.0.proj.weight"].float().to(self.device), st[f"{b}.ff.net.0.proj.bias"].float().to(self.device), self.dtype)
+        t.ff2 = self._lin(st, f"{b}.ff.net.2")
+        return t
+
+    def _pack(self, st):
+        cfg = self.cfg
+        ch = cfg.block_out_channels
+        n = len(ch)
+        e = ops.epc(self.dtype)
+        self.cin_pad = (cfg.in_channels + e - 1) // e * e
+        self.conv_in = self._conv(st, "conv_in", self.cin_pad)
+        self.te1 = self._lin(st, "time_embedding.linear_1")
+        self.te2 = self._lin(st, "time_embedding.linear_2")
+        self.freq = ops.timestep_freqs(ch[0], self.device, shift=cfg.freq_shift)
+        temb_list = []
+        self.down, self.up = [], []
+        self.attn_calls = 0
+        for i in range(n):
+            blk = _Res()
+            blk.res = [self._resnet(st, f"down_blocks.{i}.resnets.{j}", temb_list) for j in range(cfg.layers_per_block)]
+            blk.attn = [self._transformer(st, f"down_blocks.{i}.attentions.{j}", cfg.heads[i]) for j in range(cfg.layers_per_block)] \
+                if cfg.down_has_attn[i] else None
+            blk.down = self._conv(st, f"down_blocks.{i}.downsamplers.0.conv") if i < n - 1 else None
+            self.down.append(blk)
+        self.mid = _Res()
+        self.mid.res = [self._resnet(st, "mid_block.resnets.0", temb_list)]
+        self.mid.attn = [self._transformer(st, "mid_block.attentions.0", cfg.heads[n - 1])]
+        self.mid.res.append(self._resnet(st, "mid_block.resnets.1", temb_list))
+        rev_attn = list(reversed(cfg.down_has_attn))
+        for i in range(n):
+            blk = _Res()
+            blk.res = [self._resnet(st, f"up_blocks.{i}.resnets.{j}", temb_list) for j in range(cfg.layers_per_block + 1)]
+            blk.attn = [self._transformer(st, f"up_blocks.{i}.attentions.{j}", cfg.heads[n - 1 - i]) for j in range(cfg.layers_per_block + 1)] \
+                if rev_attn[i] else None
+            blk.up = self._conv(st, f"up_blocks.{i}.upsamplers.0.conv") if i < n - 1 else None
+            self.up.append(blk)
+        self.norm_out = (self._f32(st["conv_norm_out.weight"]), self._f32(st["conv_norm_out.bias"]))
+        self.conv_out = self._conv(st, "conv_out")
+        # conv_out has out_channels (4) outputs: fine for the kernel (N % 4 == 0)
+        wcat = torch.cat([w for w, _ in temb_list], 0).to(self.device)
+        self.temb_w = ops.pack_linear(wcat, self.dtype)
+        self.temb_b = torch.cat([b for _, b in temb_list], 0).float().to(self.device).contiguous()
+        self.transformers = [t for blk in self.down if blk.attn for t in blk.attn] + self.mid.attn + \
+                            [t for blk in self.up if blk.attn for t in blk.attn]
+        self.num_attention_calls = 2 * len(self.transformers)
+        self.t_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.cg_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # reference-API surface
+    # ------------------------------------------------------------------------------------------------------------
+    def set_attention_control(self, hook, controller):
+        self.hook, self.controller = hook, controller
+        self._graphs.clear()
+
+    def to(self, *a, **k):
+        return self
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None, **kw):
+        return self.forward(sample, timestep, encoder_hidden_states)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # text-side precompute: cross-attention K and V^T for all 16 blocks (constant across the sampling loop)
+    # ------------------------------------------------------------------------------------------------------------
+    def prepare_text(self, enc):
+        key = (enc.data_ptr(), enc._version, tuple(enc.shape))
+        if self._text_cache is not None and self._text_cache[0] == key:
+            return self._text_cache[1]
+        Bt, Sk, Dm = enc.shape
+        x = ops.cast(enc.float().contiguous(), self.dtype) if enc.dtype != self.dtype else enc.contiguous()
+        ld = (Sk + 7) // 8 * 8
+        kv = []
+        for t in self.transformers:
+            k = ops.linear(x, t.w_k2, None, K=Dm)
+            vt = ops.linear(x, t.w_v2, None, K=Dm, rows_per_batch=Sk, transposed_ld=ld)
+            kv.append((k, vt))
+        self._text_cache = (key, kv, enc)
+        return kv
+
+    # ------------------------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------------------------
+    def forward(self, sample, timestep, enc):
+        """sample [B,Cin,h,w] fp32 (cuda), timestep int/0-d tensor, enc [Bt,77,D] -> eps [B,Cout,h,w] fp32."""
+        sample = sample.to(self.device, torch.float32).contiguous()
+        B = sample.shape[0]
+        self.t_dev.fill_(float(timestep))
+        c = self.controller
+        if c is not None and c.context_guidance is not None:
+            self.cg_dev.fill_(float(c.context_guidance))
+        text_kv = self.prepare_text(enc)
+        if not self.use_graph:
+            return self._run(sample, text_kv)
+        sig = self._signature(B, sample.shape, enc.shape)
+        g = self._graphs.get(sig)
+        if g is None:
+            g = self._capture(sample, text_kv, sig)
+        else:
+            # replay: the controller still has to advance its counters as if every attention call had run
+            if c is not None:
+                for _ in range(self.num_attention_calls):
+                    c._tick()
+        g["x"].copy_(sample)
+        g["graph"].replay()
+        return g["out"].clone()
+
+    def _signature(self, B, shape, enc_shape):
+        c = self.controller
+        if c is None:
+            return (B, tuple(shape), tuple(enc_shape), None)
+        masks = tuple((id(m), getattr(m, "_version", 0)) for m in (c.fg_retain_mask, c.fg_ref_mask, c.local_edit_region, c.src_masks, c.tgt_masks)
+                      if m is not None)
+        return (B, tuple(shape), tuple(enc_shape), self.hook, c.use_tca, c.use_style_align, c.local_edit, c.method, tuple(c.layer_idx),
+                c.cur_att_layer, c.prompt_length, masks, id(self._text_cache[2]))
+
+    def _capture(self, sample, text_kv, sig):
+        c = self.controller
+        state = (c.cur_att_layer, c.cur_step) if c is not None else None
+        x_static = sample.clone()
+        # warm-up outside capture (lazy module loading, LDS opt-ins), then restore the controller's counters
+        self._run(x_static, text_kv)
+        if c is not None:
+            c.cur_att_layer, c.cur_step = state
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self._run(x_static, text_kv)
+        g = dict(graph=graph, x=x_static, out=out)
+        self._graphs[sig] = g
+        return g
+
+    def _gn(self, x, gb, eps, silu):
+        B, HW, C = x.shape
+        return ops.groupnorm(x, gb[0], gb[1], self.cfg.norm_num_groups, eps, silu=silu)
+
+    def _resblock(self, r, x, B, H, W, temb_all):
+        cin = x.shape[-1]
+        h = self._gn(x, r.n1, self.cfg.norm_eps, True)
+        rb = temb_all[:, r.temb_off:r.temb_off + r.cout]
+        h = ops.conv3x3(h, r.c1[0], r.c1[1], B, H, W, cin, rowbias=rb, rowbias_ld=temb_all.shape[1])
+        h = self._gn(h, r.n2, self.cfg.norm_eps, True)
+        if r.sc is not None:
+            x = ops.linear(x, r.sc[0], r.sc[1], K=cin)
+        return ops.conv3x3(h, r.c2[0], r.c2[1], B, H, W, r.cout, residual=x)
+
+    def _attention(self, t, is_cross, place, q, k, vt, ldq_view, B, S, Sk):
+        c = self.controller
+        D = t.C // t.heads
+        scale = D ** -0.5
+        if c is None:
+            return ops.attention(q, k, vt, t.heads, scale, None, Sk=Sk, C=t.C)
+        plan = c.plan(self.hook, is_cross, place, B, S, t.heads, self.device)
+        if plan["kind"] == "shared_kv":
+            rr = plan["ref_rows"]
+            kc = k[..., :t.C] if k.shape[-1] != t.C else k
+            k2 = torch.cat([kc, kc[rr]], dim=1).contiguous()                 # device-memory plumbing (non-default SSA/SDSA path)
+            vt2 = torch.cat([vt[..., :Sk], vt[rr][..., :Sk]], dim=2).contiguous()
+            return ops.attention(q, k2, vt2, t.heads, scale, plan["passes"], Sk=2 * Sk, C=t.C)
+        return ops.attention(q, k, vt, t.heads, scale, plan["passes"], Sk=Sk, C=t.C, w_dev=self.cg_dev if plan["needs_cg"] else None)
+
+    def _transformer_block(self, t, x, B, H, W, place, kv_text):
+        S, C = H * W, t.C
+        res0 = x
+        h = self._gn(x, t.norm, 1e-6, False)
+        h = ops.linear(h, t.proj_in[0], t.proj_in[1], K=C)
+        # --- self attention
+        y = ops.layernorm(h, *t.ln[0])
+        qk = ops.linear(y, t.w_qk1, None, K=C)                                  # [B,S,2C]: q | k
+        vt = ops.linear(y, t.w_v1, None, K=C, rows_per_batch=S, transposed_ld=(S + 7) // 8 * 8)   # V^T [B,C,S]
+        a = self._attention(t, False, place, qk, qk[..., C:], vt, 2 * C, B, S, S)
+        h = ops.linear(a, t.o1[0], t.o1[1], K=C, residual=h)
+        # --- cross attention
+        y = ops.layernorm(h, *t.ln[1])
+        q = ops.linear(y, t.w_q2, None, K=C)
+        k2, vt2 = kv_text
+        a = self._attention(t, True, place, q, k2, vt2, C, B, S, k2.shape[1])
+        h = ops.linear(a, t.o2[0], t.o2[1], K=C, residual=h)
+        # --- feed forward (GEGLU fused in the first GEMM's epilogue)
+        y = ops.layernorm(h, *t.ln[2])
+        y = ops.linear(y, t.ff1[0], t.ff1[1], K=C, geglu=True)
+        h = ops.linear(y, t.ff2[0], t.ff2[1], K=4 * C, residual=h)
+        return ops.linear(h, t.proj_out[0], t.proj_out[1], K=C, residual=res0)
+
+    def _run(self, sample, text_kv):
+        cfg = self.cfg
+        B, _, H, W = sample.shape
+        dt = self.dtype
+        ti = iter(text_kv)
+        # time embedding -> silu(emb) -> all 22 resnet projections in one GEMM (fp32 row biases)
+        te = ops.timestep_embed(self.t_dev, self.freq, B, dt, flip=cfg.flip_sin_to_cos)
+        e1 = ops.linear(te, self.te1[0], self.te1[1], K=self.te1[2], silu=True)
+        e2 = ops.linear(e1, self.te2[0], self.te2[1], K=self.te2[2], silu=True)     # = silu(time_embedding(t_emb))
+        temb_all = ops.linear(e2, self.temb_w, self.temb_b, K=self.te2[0].shape[0], out_f32=True)
+        x = ops.pack_nchw(sample, list(range(B)), self.cin_pad, dt)
+        x = ops.conv3x3(x, self.conv_in[0], self.conv_in[1], B, H, W, self.cin_pad)
+        skips = [(x, H, W)]
+        n = len(self.down)
+        for i, blk in enumerate(self.down):
+            for j, r in enumerate(blk.res):
+                x = self._resblock(r, x, B, H, W, temb_all)
+                if blk.attn:
+                    x = self._transformer_block(blk.attn[j], x, B, H, W, "down", next(ti))
+                skips.append((x, H, W))
+            if blk.down is not None:
+                C = x.shape[-1]
+                x = ops.conv3x3(x, blk.down[0], blk.down[1], B, H, W, C, stride=2)
+                H, W = (H + 1) // 2, (W + 1) // 2
+                skips.append((x, H, W))
+        x = self._resblock(self.mid.res[0], x, B, H, W, temb_all)
+        x = self._transformer_block(self.mid.attn[0], x, B, H, W, "mid", next(ti))
+        x = self._resblock(self.mid.res[1], x, B, H, W, temb_all)
+        for i, blk in enumerate(self.up):
+            for j, r in enumerate(blk.res):
+                s, sh, sw = skips.pop()
+                assert (sh, sw) == (H, W)
+                x = ops.concat(x, s)
+                x = self._resblock(r, x, B, H, W, temb_all)
+                if blk.attn:
+                    x = self._transformer_block(blk.attn[j], x, B, H, W, "up", next(ti))
+            if blk.up is not None:
+                C = x.shape[-1]
+                x = ops.conv3x3(x, blk.up[0], blk.up[1], B, H, W, C, upsample=True)
+                H, W = 2 * H, 2 * W
+        x = self._gn(x, self.norm_out, cfg.norm_eps, True)
+        eps = ops.conv3x3(x, self.conv_out[0], self.conv_out[1], B, H, W, x.shape[-1], out_f32=True)
+        return ops.nhwc_to_nchw_f32(eps, cfg.out_channels, H, W)
