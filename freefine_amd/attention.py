@@ -76,6 +76,13 @@ def _resize_flat(mask, seq, normalise):
 
 
 class Attention_Modulator(AttentionControl):
+    _MASK_ATTRS = ("fg_retain_mask", "fg_retain_mask_st2", "fg_ref_mask", "obj_mask", "local_edit_region", "src_masks", "tgt_masks")
+
+    def __setattr__(self, name, value):
+        if name in Attention_Modulator._MASK_ATTRS:      # any (re)assignment of a mask invalidates the cached device vectors
+            object.__setattr__(self, "_mask_epoch", getattr(self, "_mask_epoch", 0) + 1)
+        object.__setattr__(self, name, value)
+
     def __init__(self, start_layer=None):
         super().__init__()
         self.step_num = 0
@@ -129,12 +136,14 @@ class Attention_Modulator(AttentionControl):
             self.cur_step += 1
             self.between_steps()
 
-    # ---- mask vectors (device byte / float vectors per sequence length, cached per mask object + version) ----------
-    def _vectors(self, mask, seq, device, kind):
-        key = (id(mask), mask._version, seq, kind, str(device))
-        hit = self._vec_cache.get(key)
-        if hit is not None and hit[0] is mask:
-            return hit[1]
+    # ---- mask vectors: STATIC device buffers per (role, sequence length), refreshed in place when the mask changes,
+    #      so a captured hipGraph of the UNet forward stays valid from one edit to the next -------------------------
+    def _vectors(self, role, mask, seq, device, kind):
+        key = (role, seq, kind, str(device))
+        tag = (self._mask_epoch, mask.data_ptr(), mask._version, tuple(mask.shape), mask.dtype)
+        ent = self._vec_cache.get(key)
+        if ent is not None and ent["tag"] == tag:
+            return ent["out"]
         if kind == "key":      # FG keys: bytes (m==1); counts for the uniform-softmax degenerate case
             m = _resize_flat(mask, seq, True)
             vals = set(m.unique().tolist())
@@ -142,19 +151,26 @@ class Attention_Modulator(AttentionControl):
                 raise NotImplementedError(f"non-binary attention mask values {sorted(vals)}: the reference would add them as "
                                           "score biases (attention.py:856-858); only {0,1} masks are supported by the fused kernel")
             fg = (m == 1).to(torch.uint8)
-            out = dict(fg=fg.to(device), bg=(1 - fg).to(device), n1=int(fg.sum()), n0=int((1 - fg).sum()))
+            host = dict(fg=fg, bg=1 - fg, n1=int(fg.sum()), n0=int((1 - fg).sum()))
         elif kind == "query_norm":   # T = resized, normalised target mask per query (TCA): float + byte selector
             m = _resize_flat(mask, seq, True)
-            out = dict(f=m.float().to(device), sel=(m > 0).to(torch.uint8).to(device), binary=bool(set(m.unique().tolist()) <= {0, 1}))
+            host = dict(f=m.float(), sel=(m > 0).to(torch.uint8), binary=bool(set(m.unique().tolist()) <= {0, 1}))
         elif kind == "query_raw":    # R and (1 - R) for the local cross-attn blend, (1-R) in the mask's own dtype
             m = _resize_flat(mask, seq, False)
-            out = dict(f=m.float().to(device), omf=(1 - m).float().to(device))
+            host = dict(f=m.float(), omf=(1 - m).float())
         else:
             raise ValueError(kind)
-        if len(self._vec_cache) > 256:
-            self._vec_cache.clear()
-        self._vec_cache[key] = (mask, out)
-        return out
+        if ent is None:
+            ent = dict(out={k: (v.to(device) if torch.is_tensor(v) else v) for k, v in host.items()})
+            self._vec_cache[key] = ent
+        else:
+            for k, v in host.items():
+                if torch.is_tensor(v):
+                    ent["out"][k].copy_(v)
+                else:
+                    ent["out"][k] = v
+        ent["tag"] = tag
+        return ent["out"]
 
     @staticmethod
     def _kflags(v, sel1=True, sel0=False):
@@ -186,8 +202,8 @@ class Attention_Modulator(AttentionControl):
 
     def _plan_tca_edit(self, B, S, device):
         assert B == 4, "edit hook expects rows [u_e, u_r, c_e, c_r]"
-        kv = self._vectors(self.fg_ref_mask, S, device, "key")
-        qv = self._vectors(self.fg_retain_mask, S, device, "query_norm")
+        kv = self._vectors("fg_ref", self.fg_ref_mask, S, device, "key")
+        qv = self._vectors("fg_retain", self.fg_retain_mask, S, device, "query_norm")
         ref_rows = [1, 1, 3, 3]
         flags = L.ATT_HEAD_RULE | self._kflags(kv, True, True)
         if self.method == "tca":
@@ -203,7 +219,7 @@ class Attention_Modulator(AttentionControl):
 
     def _plan_tca_bg(self, B, S, device):
         assert B == 4
-        kv = self._vectors(self.fg_retain_mask, S, device, "key")   # the hole; keys allowed OUTSIDE it
+        kv = self._vectors("fg_retain", self.fg_retain_mask, S, device, "key")   # the hole; keys allowed OUTSIDE it
         ref_rows = [1, 1, 3, 3]
         flags = L.ATT_HEAD_RULE | (L.ATT_UNIFORM_SEL1 if kv["n0"] == 0 else 0)
         if self.method == "tca":
@@ -226,8 +242,8 @@ class Attention_Modulator(AttentionControl):
             p_self = [None if b in edit_rows else AttnEntrySpec(b, b) for b in range(B)]
         passes = [p_self]
         for i in range(R):
-            kv = self._vectors(self.src_masks[i], S, device, "key")
-            qv = self._vectors(self.tgt_masks[i], S, device, "query_norm")
+            kv = self._vectors(f"src{i}", self.src_masks[i], S, device, "key")
+            qv = self._vectors(f"tgt{i}", self.tgt_masks[i], S, device, "query_norm")
             fl = self._kflags(kv, True, False)
             w = (0.0, 1.0) if tca else (1.0, 0.0)
             passes.append([AttnEntrySpec(b, 1 + i, w[0], w[1], wq=qv["f"], kmask=kv["fg"], flags=fl) if b in edit_rows else None
@@ -236,7 +252,7 @@ class Attention_Modulator(AttentionControl):
 
     def _plan_cross_local(self, B, S, device):
         assert B == 4
-        rv = self._vectors(self.local_edit_region, S, device, "query_raw")
+        rv = self._vectors("local_edit", self.local_edit_region, S, device, "query_raw")
         p0 = [AttnEntrySpec(0, 0), AttnEntrySpec(1, 1), AttnEntrySpec(2, 2, wq=rv["f"]), AttnEntrySpec(1, 1)]
         p1 = [None, None, AttnEntrySpec(0, 0, wq=rv["omf"]), None]
         return dict(kind="passes", passes=[p0, p1], needs_cg=False, branch="cross_local")
@@ -248,7 +264,7 @@ class Attention_Modulator(AttentionControl):
         nu = B - 1
         passes = []
         for p in range(P):
-            rv = self._vectors(self.tgt_masks[p], S, device, "query_raw")
+            rv = self._vectors(f"tgt{p}", self.tgt_masks[p], S, device, "query_raw")
             rows = [AttnEntrySpec(b, b) if p == 0 else None for b in range(nu)]
             rows.append(AttnEntrySpec(nu, nu + p, wq=rv["f"]))
             passes.append(rows)
@@ -258,8 +274,10 @@ class Attention_Modulator(AttentionControl):
         ref_rows = [1] * (B // 2) + [B // 2 + 1] * (B // 2)
         kmask, flags = None, 0
         if self.method == "sdsa":
-            kv = self._vectors(self.fg_ref_mask, S, device, "key")
-            kmask = torch.cat([torch.ones(S, dtype=torch.uint8, device=device), kv["fg"]])
+            kv = self._vectors("fg_ref", self.fg_ref_mask, S, device, "key")
+            buf = self._vec_cache.setdefault(("sdsa_cat", S, str(device)), torch.ones(2 * S, dtype=torch.uint8, device=device))
+            buf[S:].copy_(kv["fg"])
+            kmask = buf
             flags = L.ATT_HEAD_RULE
         passes = [[AttnEntrySpec(b, b, kmask=kmask, flags=flags) for b in range(B)]]
         return dict(kind="shared_kv", passes=passes, ref_rows=ref_rows, needs_cg=False, branch=self.method)

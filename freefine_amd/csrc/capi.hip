@@ -102,7 +102,8 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
     REQUIRE(d->A && d->W && d->out, "igemm: null A/W/out");
     REQUIRE(aligned16(d->A) && aligned16(d->W) && aligned16(d->out), "igemm: A/W/out must be 16-byte aligned");
     REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "igemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
-    REQUIRE(d->Kpad >= d->K && d->Kpad % kstage == 0, "igemm: Kpad=%d must be >= K=%d and a multiple of %d", d->Kpad, d->K, kstage);
+    REQUIRE(d->Kpad >= d->K && d->Kpad % epc == 0, "igemm: Kpad=%d (row stride of W) must be >= K=%d and a multiple of %d", d->Kpad, d->K, epc);
+    (void)kstage;
     REQUIRE(d->K % epc == 0, "igemm: K=%d must be a multiple of %d", d->K, epc);
     REQUIRE(d->rows_per_batch > 0, "igemm: rows_per_batch must be > 0");
     if (d->conv) {

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             rb[i] = u32x4{0, 0, 0, 0};
-            if (b_ok[i]) rb[i] = *reinterpret_cast<const u32x4*>(Wg + b_base[i] + kk);  // W is zero-padded to Kpad
+            if (b_ok[i] && kk < p.K) rb[i] = *reinterpret_cast<const u32x4*>(Wg + b_base[i] + kk);  // Kpad = row stride of W
         }
     };
     auto write_lds = [&](int buf) {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.Kpad / BKE;
+    const int nk = (p.K + BKE - 1) / BKE;
     issue_loads(0);
     write_lds(0);
     __syncthreads();

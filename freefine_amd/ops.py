@@ -81,8 +81,8 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
     d = L.IgemmDesc()
     d.A, d.W = x.data_ptr(), w.data_ptr()
     d.bias, d.rowbias, d.residual = _p(bias), _p(rowbias), _p(residual)
-    d.M, d.N, d.K, d.Kpad = M, N, K, w.shape[1]
-    d.lda = x.shape[-1]
+    d.M, d.N, d.K, d.Kpad = M, N, K, w.stride(0)    # Kpad = row stride of W (an activation view can serve as W)
+    d.lda = x.stride(-2) if x.ndim > 1 else x.shape[-1]
     d.rows_per_batch = rows_per_batch or M
     d.ldrb = rowbias.stride(0) if rowbias is not None else 0
     flags = 0

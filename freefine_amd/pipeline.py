@@ -1,0 +1,663 @@
+"""FreeFinePipeline on the MI355X engine: same class name, method names, keyword arguments and return conventions as the
+reference pipeline (/root/reference/src/demo/model.py:103-1804), so the GeoBench drivers' and notebooks' call pattern
+(`FreeFinePipeline.from_pretrained(...).to(device)`, `model.scheduler = DDIMScheduler.from_config(...)`,
+`register_attention_control(model, controller)`, `model.modify_unet_forward()`, `model.FreeFine_generation(...)`)
+works unchanged -- but every tensor op of the hot path runs in libfreefine_hip.so (freefine_amd/unet.py, vae.py, ops.py).
+
+Host-side logic that stays Python (like the reference): loop control, the scalar DDIM coefficients (computed with the
+same fp32 torch scalar arithmetic as the reference), mask preparation on uint8 tensors (incl. its wrap-around,
+SURVEY 0.7) and the controller wiring.  Noise for the masked DDPM step is drawn from torch's GLOBAL CPU generator in
+the reference's order (model.py:185-188 with generator=None; exactly n draws after seed_everything), so trajectories are
+comparable with the CPU oracle on identical seeds; set `noise_device="cuda"` to draw on the GPU instead.
+"""
+import os
+import random
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .attention import Attention_Modulator
+from .config import UNetConfig, VAEConfig
+from .scheduler import DDIMScheduler
+from .text import ByteTokenizer, SyntheticTextEncoder
+from .unet import HipUNet
+from .vae import HipVAE
+from .weights import load_safetensors_dir, synthetic_state, unet_param_shapes, vae_param_shapes
+
+
+def seed_everything(seed):
+    """pytorch_lightning.seed_everything as used at model.py:1018."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    return seed
+
+
+def _dilate(mask, k):
+    from scipy import ndimage
+    return ndimage.maximum_filter(mask.astype(np.uint8), size=(k, k), mode="constant", cval=0)  # == cv2.dilate(ones(k,k))
+
+
+class FreeFinePipeline:
+    _progress_bar_config = {}
+
+    def __init__(self, unet, vae, tokenizer, text_encoder, scheduler, device="cuda:0"):
+        self.unet, self.vae, self.tokenizer, self.text_encoder, self.scheduler = unet, vae, tokenizer, text_encoder, scheduler
+        self.device = torch.device(device)
+        self.controller = None
+        self.method_type = None
+        self.noise_device = "cpu"
+
+    # ------------------------------------------------------------------------------------------------------------
+    # construction (freefine_batch_infer_2d.py:148-157)
+    # ------------------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, path, torch_dtype=torch.float32, device="cuda:0", seed=0, **kw):
+        """`path` is either a HF-layout Stable-Diffusion folder (unet/, vae/ safetensors + config.json; tokenizer/,
+        text_encoder/ loaded through transformers when present) or "synthetic:<unet preset>[:<vae preset>]" for
+        seeded random weights of that architecture (no checkpoints exist in the build environment).
+        torch_dtype float32 -> exact-fp32 parity mode; float16/bfloat16 -> bf16 MFMA fast mode."""
+        dtype = torch.float32 if torch_dtype == torch.float32 else torch.bfloat16
+        if path.startswith("synthetic:"):
+            parts = path.split(":")
+            ucfg = UNetConfig.preset(parts[1])
+            vcfg = VAEConfig.preset(parts[2] if len(parts) > 2 else ("tiny" if parts[1].startswith("tiny") else "sd"))
+            ust = synthetic_state(unet_param_shapes(ucfg), seed)
+            vst = synthetic_state(vae_param_shapes(vcfg), seed + 1)
+            tok, enc = ByteTokenizer(), SyntheticTextEncoder(ucfg.cross_attention_dim)
+            sched = DDIMScheduler()
+        else:
+            ucd, ust = load_safetensors_dir(path, "unet")
+            vcd, vst = load_safetensors_dir(path, "vae")
+            ucfg = UNetConfig.from_diffusers(ucd)
+            vcfg = VAEConfig(block_out_channels=tuple(vcd["block_out_channels"]), layers_per_block=vcd["layers_per_block"],
+                             latent_channels=vcd["latent_channels"], norm_num_groups=vcd.get("norm_num_groups", 32),
+                             scaling_factor=0.18215)
+            import json
+            sc = {}
+            sp = os.path.join(path, "scheduler", "scheduler_config.json")
+            if os.path.exists(sp):
+                with open(sp) as f:
+                    sc = {k: v for k, v in json.load(f).items() if k in ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule",
+                                                                          "steps_offset", "set_alpha_to_one", "prediction_type")}
+            sched = DDIMScheduler(**sc)
+            from transformers import CLIPTextModel, CLIPTokenizer
+            tok = CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer"))
+            enc = CLIPTextModel.from_pretrained(os.path.join(path, "text_encoder")).eval()
+        return cls.from_state(ucfg, ust, vcfg, vst, tok, enc, sched, dtype, device)
+
+    @classmethod
+    def from_state(cls, ucfg, ustate, vcfg, vstate, tokenizer, text_encoder, scheduler=None, dtype=torch.float32, device="cuda:0"):
+        unet = HipUNet(ucfg, ustate, dtype=dtype, device=device)
+        vae = HipVAE(vcfg, vstate, dtype=dtype, device=device)
+        return cls(unet, vae, tokenizer, text_encoder, scheduler or DDIMScheduler(), device)
+
+    def to(self, device=None, *a, **k):
+        return self
+
+    def enable_attention_slicing(self, *a, **k):     # accepted and ignored: the fused kernels never materialise scores
+        pass
+
+    def enable_xformers_memory_efficient_attention(self, *a, **k):
+        pass
+
+    def modify_unet_forward(self):                   # the executor already returns a bare tensor (attention.py:214-223)
+        pass
+
+    # ------------------------------------------------------------------------------------------------------------
+    # scheduler steps
+    # ------------------------------------------------------------------------------------------------------------
+    def inv_step(self, model_output, timestep, x, eta=0., verbose=False):
+        """model.py:109-132"""
+        next_step = int(timestep)
+        t = min(next_step - self.scheduler.config.num_train_timesteps // self.scheduler.num_inference_steps, 999)
+        a_t = self.scheduler.alphas_cumprod[t] if t >= 0 else self.scheduler.final_alpha_cumprod
+        a_next = self.scheduler.alphas_cumprod[next_step]
+        c_bt, c_at = ((1 - a_t) ** 0.5).item(), (a_t ** 0.5).item()
+        c_an, c_bn = (a_next ** 0.5).item(), ((1 - a_next) ** 0.5).item()
+        return ops.ddim_inv_step(model_output.contiguous(), x.contiguous(), c_bt, c_at, c_an, c_bn, want_pred_x0=True)
+
+    def _get_variance(self, timestep, prev_timestep):
+        a_t = self.scheduler.alphas_cumprod[timestep]
+        a_prev = self.scheduler.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.scheduler.final_alpha_cumprod
+        return ((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)
+
+    def ctrl_step(self, model_output, timestep, x, mask, eta=0.0, generator=None, noise=None):
+        """model.py:134-198.  `mask` is the [h,w] tensor in its pipeline dtype (uint8): (1 - mask) is evaluated in that dtype."""
+        t = int(timestep)
+        prev_t = t - self.scheduler.config.num_train_timesteps // self.scheduler.num_inference_steps
+        a_t = self.scheduler.alphas_cumprod[t]
+        a_prev = self.scheduler.alphas_cumprod[prev_t] if prev_t > 0 else self.scheduler.final_alpha_cumprod
+        std = eta * self._get_variance(t, prev_t).to(torch.float32) ** 0.5
+        rows = model_output.shape[0]
+        if rows == 2:
+            stds, masked = [std, torch.zeros_like(std)], [1, 0]
+        else:
+            stds, masked = [std] * rows, [1] * rows
+        if mask is None:
+            masked = [0] * rows
+            m_host = torch.ones(x.shape[-2:], dtype=torch.float32)
+        else:
+            m_host = mask.detach().cpu()
+        m_f = m_host.float().reshape(-1).to(self.device)
+        om_f = (1 - m_host).float().reshape(-1).to(self.device)
+        c_dirm = [((1 - a_prev - s ** 2) ** 0.5).item() for s in stds]
+        if eta > 0 and noise is None:
+            if self.noise_device == "cpu":
+                noise = torch.randn(model_output.shape, generator=generator, dtype=torch.float32).to(self.device)
+            else:
+                noise = torch.randn(model_output.shape, generator=generator, device=self.device, dtype=torch.float32)
+        return ops.ddim_ctrl_step(model_output.contiguous(), x.contiguous(), noise if eta > 0 else None, m_f, om_f,
+                                  ((1 - a_t) ** 0.5).item(), (a_t ** 0.5).item(), (a_prev ** 0.5).item(), ((1 - a_prev) ** 0.5).item(),
+                                  c_dirm, [s.item() for s in stds], masked, want_pred_x0=True)
+
+    def linear_param(self, t, t1, t0, t2, end_scale=0.5):
+        """model.py:438-455"""
+        if t < t1 or t > t2:
+            raise ValueError(f"t must be in [{t1}, {t2}]")
+        if t <= t0:
+            return 1 + (end_scale - 1) / (t0 - t1) * (t - t1)
+        return end_scale + (-end_scale / (t2 - t0)) * (t - t0)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # VAE bracket / text
+    # ------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def image2latent(self, image):
+        """model.py:223-268: uint8 HWC ndarray / float NCHW tensor in [-1,1] -> latent mean * 0.18215"""
+        if isinstance(image, np.ndarray):
+            image = torch.from_numpy(image)
+        if image.dtype == torch.uint8:                  # HWC / NHWC bytes: x/127.5-1 happens in the VAE's first kernel
+            return self.vae.encode_mean_scaled(img_u8=image[None] if image.ndim == 3 else image)
+        if image.ndim == 3:
+            image = image.permute(2, 0, 1).unsqueeze(0)
+        return self.vae.encode_mean_scaled(x_nchw=image)
+
+    @torch.no_grad()
+    def latent2image(self, latents, return_type="np"):
+        image = self.vae.decode_image(latents.detach())
+        if return_type == "np":
+            return (image.cpu().permute(0, 2, 3, 1).numpy()[0] * 255).astype(np.uint8)
+        return image
+
+    @torch.no_grad()
+    def _encode_text(self, prompts):
+        ids = self.tokenizer(prompts, padding="max_length", max_length=77, return_tensors="pt").input_ids
+        out = self.text_encoder(ids)[0]
+        return out.to(self.device, torch.float32).contiguous()
+
+    @torch.no_grad()
+    def get_text_embeddings(self, prompt):
+        return self._encode_text(prompt)
+
+    def preprocess_image(self, image, device=None):
+        return (torch.from_numpy(image).float() / 127.5 - 1).permute(2, 0, 1).unsqueeze(0).to(self.device)
+
+    def resize_img(self, img, size=None):
+        """model.py:1332-1340: PIL thumbnail (never upscales); a no-op for the <=512 inputs of the drivers."""
+        if max(img.shape[:2]) <= max(size):
+            return img
+        from PIL import Image
+        im = Image.fromarray(img)
+        im.thumbnail(size, Image.Resampling.LANCZOS)
+        return np.array(im)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # loops
+    # ------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def invert(self, image, prompt, num_inference_steps=50, num_actual_inference_steps=None, guidance_scale=7.5, eta=0.0,
+               return_intermediates=False, verbose=False, **kwds):
+        """model.py:816-925 (HOT LOOP 1)"""
+        batch_size = image.shape[0]
+        if isinstance(prompt, list):
+            if batch_size == 1:
+                image = image.expand(len(prompt), -1, -1, -1)
+        elif isinstance(prompt, str) and batch_size > 1:
+            prompt = [prompt] * batch_size
+        text = self._encode_text(prompt)
+        latents = self.image2latent(image)
+        if guidance_scale > 1.:
+            text = torch.cat([self._encode_text([""] * batch_size), text], dim=0)
+            self.controller.use_cfg = True
+        self.scheduler.set_timesteps(num_inference_steps)
+        latents_list = [latents]
+        for i, t in enumerate(reversed(self.scheduler.timesteps)):
+            if num_actual_inference_steps is not None and i >= num_actual_inference_steps:
+                continue
+            model_inputs = torch.cat([latents] * 2) if guidance_scale > 1. else latents
+            noise_pred = self.unet(model_inputs, t, encoder_hidden_states=text)
+            if guidance_scale > 1.:
+                eu, ec = noise_pred.chunk(2, dim=0)
+                noise_pred = ops.cfg_masked(eu.contiguous(), ec.contiguous(), None, guidance_scale)
+            latents, _ = self.inv_step(noise_pred, t, latents)
+            latents_list.append(latents)
+        if return_intermediates:
+            return latents, latents_list
+        return latents
+
+    def _configure_method(self, method_type, share_attn=True):
+        self.method_type = method_type
+        c = self.controller
+        if share_attn:
+            if method_type == "tca":
+                c.use_tca, c.layer_idx, c.method = True, list(range(10, 16)), "tca"
+            elif method_type in ("mmsa", "mmsa_es"):
+                c.use_tca, c.layer_idx, c.method = True, list(range(10, 16)), "mmsa"
+            elif method_type in ("ssa", "sdsa"):
+                c.use_style_align, c.method = True, method_type
+        c.use_cfg = True
+
+    def _mask_f(self, mask):
+        return mask.detach().cpu().float().reshape(-1).to(self.device)
+
+    @torch.no_grad()
+    def forward_sampling(self, prompt, prompt_embeds=None, refer_latents=None, batch_size=1, end_step=None, height=512, width=512,
+                         num_inference_steps=50, num_actual_inference_steps=None, guidance_scale=7.5, latents=None,
+                         unconditioning=None, neg_prompt=None, return_intermediates=False, eta=0.0, end_scale=0.5,
+                         local_var_reg=None, completion_mask_cfg=None, local_edit_text=True, share_attn=True, method_type=None,
+                         verbose=False, local_perturbation=True, **kwds):
+        """model.py:476-622 (HOT LOOP 2, edit)"""
+        assert guidance_scale > 1.0, "USING THIS MODULE CFG Must > 1.0"
+        self._configure_method(method_type, share_attn)
+        self.controller.local_edit = local_edit_text
+        if prompt_embeds is None:
+            if isinstance(prompt, list):
+                batch_size = len(prompt)
+            elif isinstance(prompt, str) and batch_size > 1:
+                prompt = [prompt] * batch_size
+            text = self._encode_text(prompt)
+        else:
+            batch_size, text = prompt_embeds.shape[0], prompt_embeds.to(self.device, torch.float32)
+        if latents is None:
+            latents = torch.randn((batch_size, self.unet.in_channels, height // 8, width // 8)).to(self.device)
+        text = torch.cat([self._encode_text([neg_prompt or ""] * batch_size), text], dim=0).contiguous()
+        self.scheduler.set_timesteps(num_inference_steps)
+        latents_list = [latents]
+        start_step = num_inference_steps - num_actual_inference_steps
+        cfg_f = self._mask_f(completion_mask_cfg) if local_edit_text else None
+        for i, t in enumerate(self.scheduler.timesteps):
+            if i < start_step:
+                continue
+            ref_latent = refer_latents[i - start_step + 1][1]
+            if latents.shape[0] > 1:
+                latents[1:] = ref_latent
+            else:
+                latents = torch.cat([latents, ref_latent[None] if ref_latent.ndim == 3 else ref_latent])
+            if method_type == "tca":
+                self.controller.context_guidance = self.linear_param(i, start_step, end_step, num_inference_steps, end_scale=end_scale)
+            elif method_type == "mmsa_es" and i >= end_step:
+                self.controller.use_tca = False
+            noise_pred = self.unet(torch.cat([latents] * 2), t, encoder_hidden_states=text)
+            eu, ec = noise_pred.chunk(2, dim=0)
+            noise_pred = ops.cfg_masked(eu.contiguous(), ec.contiguous(), cfg_f, guidance_scale)
+            mask = local_var_reg if local_perturbation else torch.ones_like(local_var_reg)
+            latents = self.ctrl_step(noise_pred, t, latents, mask, eta=eta)[0]
+            latents_list.append(latents)
+        image = self.latent2image(latents, return_type="pt")
+        return (image, latents_list) if return_intermediates else (image, None)
+
+    @torch.no_grad()
+    def forward_sampling_background_gen(self, prompt, batch_size=1, end_step=None, height=512, width=512, num_inference_steps=50,
+                                        num_actual_inference_steps=None, guidance_scale=7.5, latents=None, refer_latents=None,
+                                        unconditioning=None, neg_prompt=None, return_intermediates=False, eta=0.0,
+                                        local_var_reg=None, local_cfg_reg=None, local_text_edit=True, share_attn=True,
+                                        method_type="tca", verbose=False, local_perturbation=True, end_scale=0.5,
+                                        latent_blended=True, blend_range=(0, 40), **kwds):
+        """model.py:656-812 (removal / background generation); latent_blended / blend_range accepted but inert (:805-806)"""
+        assert guidance_scale > 1.0, "USING THIS MODULE CFG Must > 1.0"
+        self._configure_method(method_type, share_attn)
+        self.controller.local_edit = local_text_edit
+        if isinstance(prompt, list):
+            batch_size = len(prompt)
+        elif isinstance(prompt, str) and batch_size > 1:
+            prompt = [prompt] * batch_size
+        text = self._encode_text(prompt)
+        if latents is None:
+            latents = torch.randn((batch_size, self.unet.in_channels, height // 8, width // 8)).to(self.device)
+        text = torch.cat([self._encode_text([neg_prompt or ""] * batch_size), text], dim=0).contiguous()
+        self.scheduler.set_timesteps(num_inference_steps)
+        latents_list = [latents]
+        start_step = num_inference_steps - num_actual_inference_steps
+        cfg_f = self._mask_f(local_cfg_reg) if local_text_edit else None
+        for i, t in enumerate(self.scheduler.timesteps):
+            if i < start_step:
+                continue
+            ref_latent = refer_latents[i - start_step]
+            if latents.shape[0] > 1:
+                latents = latents[0].unsqueeze(0)
+            latents = torch.cat([latents, ref_latent], dim=0)
+            if method_type == "tca":
+                self.controller.context_guidance = self.linear_param(i, start_step, end_step, num_inference_steps, end_scale=end_scale)
+            elif method_type == "mmsa_es" and i >= end_step:
+                self.controller.use_tca = False
+            noise_pred = self.unet(torch.cat([latents] * 2), t, encoder_hidden_states=text)
+            eu, ec = noise_pred.chunk(2, dim=0)
+            noise_pred = ops.cfg_masked(eu.contiguous(), ec.contiguous(), cfg_f, guidance_scale)
+            mask = local_var_reg if local_perturbation else torch.ones_like(local_var_reg)
+            latents = self.ctrl_step(noise_pred, t, latents, mask, eta=eta)[0]
+            latents_list.append(latents[0])
+        image = self.latent2image(latents, return_type="pt")
+        return (image, latents_list) if return_intermediates else (image, None)
+
+    @torch.no_grad()
+    def forward_sampling_compose(self, prompt, prompt_embeds=None, refer_latents=None, batch_size=1, end_step=None, height=512,
+                                 width=512, num_inference_steps=50, num_actual_inference_steps=None, guidance_scale=7.5,
+                                 latents=None, unconditioning=None, neg_prompt=None, return_intermediates=False, eta=0.0,
+                                 end_scale=0.5, local_var_reg=None, local_edit_text=True, cfg_masks_tensor=None, share_attn=True,
+                                 method_type=None, verbose=False, local_perturbation=True, **kwds):
+        """model.py:301-435 (cross-image composition / appearance transfer): UNet batch [edit, ref_1..ref_R, edit]"""
+        assert guidance_scale > 1.0, "USING THIS MODULE CFG Must > 1.0"
+        self._configure_method(method_type, share_attn)
+        self.controller.local_edit = local_edit_text
+        prompt.append("")                                      # the reference mutates the caller's list too (model.py:352)
+        self.controller.prompt_length = len(prompt)
+        text = self._encode_text(prompt)
+        if latents is None:
+            latents = torch.randn((batch_size, self.unet.in_channels, height // 8, width // 8)).to(self.device)
+        text = torch.cat([self._encode_text([neg_prompt or ""] * batch_size), text], dim=0).contiguous()
+        self.scheduler.set_timesteps(num_inference_steps)
+        latents_list = [latents]
+        start_step = num_inference_steps - num_actual_inference_steps
+        cfg_f = self._mask_f(cfg_masks_tensor) if local_edit_text else None
+        for i, t in enumerate(self.scheduler.timesteps):
+            if i < start_step:
+                continue
+            ref_latent = refer_latents[i - start_step + 1][1:]
+            if latents.shape[0] > 1:
+                latents[1:] = ref_latent
+            else:
+                latents = torch.cat([latents, ref_latent])
+            if method_type == "tca":
+                self.controller.context_guidance = self.linear_param(i, start_step, end_step, num_inference_steps, end_scale=end_scale)
+            elif method_type == "mmsa_es" and i >= end_step:
+                self.controller.use_tca = False
+            noise_pred = self.unet(torch.cat([latents, latents[0][None]]), t, encoder_hidden_states=text)
+            eu, ec = noise_pred[0][None].contiguous(), noise_pred[-1][None].contiguous()
+            noise_pred = ops.cfg_masked(eu, ec, cfg_f, guidance_scale)
+            mask = local_var_reg if local_perturbation else torch.ones_like(local_var_reg)
+            latents = self.ctrl_step(noise_pred, t, latents[0][None].contiguous(), mask, eta=eta)[0]
+            latents_list.append(latents[0])
+        image = self.latent2image(latents, return_type="pt")[0]
+        return (image, latents_list) if return_intermediates else (image, None)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # masks (model.py:927-934, 1431-1639) -- uint8 tensors on the host, arithmetic exactly as the reference
+    # ------------------------------------------------------------------------------------------------------------
+    def dilate_mask(self, mask, dilate_factor=15):
+        return _dilate(mask, dilate_factor)
+
+    def mask_reduce_dim(self, mask):
+        return mask[:, :, 0] if mask.ndim == 3 else mask
+
+    def prepare_tensor_mask(self, mask, sup_res_w, sup_res_h, binary=True):
+        if mask.ndim == 3:
+            mask = mask[:, :, 0]
+        t = F.interpolate(torch.tensor(mask)[None, None], (sup_res_h, sup_res_w), mode="nearest")[0, 0]
+        if binary:
+            t[t > 0.0] = 1.0
+        else:
+            t = t.float() / t.max()
+        return t
+
+    @staticmethod
+    def _nearest(t, hw):
+        return F.interpolate(t[None, None], hw, mode="nearest")[0, 0]
+
+    @torch.no_grad()
+    def prepare_various_mask(self, shifted_mask, ori_mask, draw_mask, sup_res_w, sup_res_h, init_code, verbose=False,
+                             use_auto_draw=False, cons_area=None, reduce_inp_artifacts=False):
+        ptm = lambda m: self.prepare_tensor_mask(m, sup_res_w, sup_res_h)
+        if not use_auto_draw:
+            shifted, ori = ptm(shifted_mask), ptm(ori_mask)
+            flexible = ptm(draw_mask) * (1 - shifted)
+            fg = flexible + shifted
+            fg[fg > 0] = 1.0
+            complete = flexible
+            if not reduce_inp_artifacts:
+                local_var = flexible
+            else:
+                assert cons_area is not None, "for auto artifact expansion use cons area "
+                dil, cons = ptm(self.dilate_mask(ori_mask, 30)), ptm(cons_area)
+                local_var = (1 - cons) * (1 - shifted) * dil + flexible
+                local_var[local_var > 0] = 1
+        else:
+            assert cons_area is not None, "for auto draw better use cons area "
+            dil_tgt = ptm(self.dilate_mask(shifted_mask, 15))
+            shifted, ori, cons = ptm(shifted_mask), ptm(ori_mask), ptm(cons_area)
+            fg = shifted
+            cons = cons - ori                                   # uint8: wraps where ori & ~cons
+            if not reduce_inp_artifacts:
+                complete = (1 - cons) * (1 - shifted) * dil_tgt
+            else:
+                complete = ptm(self.dilate_mask(ori_mask, 30)) + dil_tgt
+                complete[complete > 0] = 1
+                complete *= (1 - cons) * (1 - shifted)
+            local_var = complete
+        hw = (init_code.shape[2], init_code.shape[3])
+        return fg, shifted, ori, self._nearest(complete, hw), self._nearest(local_var, hw)
+
+    @torch.no_grad()
+    def prepare_mask_bggen(self, mask, sup_res_w, sup_res_h, init_code):
+        t = self.prepare_tensor_mask(mask, sup_res_w, sup_res_h)
+        return t, self._nearest(t, (init_code.shape[2], init_code.shape[3]))
+
+    @torch.no_grad()
+    def prepare_composition_masks(self, ori_mask_lists, tgt_mask_lists, sup_res_w, sup_res_h, init_code, dil_completion=False,
+                                  dil_factor=15, draw_mask=None, appearance_transfer=False):
+        ptm = lambda m: self.prepare_tensor_mask(m, sup_res_w, sup_res_h)
+        hw = (init_code.shape[2], init_code.shape[3])
+        ori = [ptm(m) for m in ori_mask_lists]
+        tgt = []
+        lp, fg = torch.zeros_like(ori[0]), torch.zeros_like(ori[0])
+        if appearance_transfer:
+            for sm in tgt_mask_lists:
+                d = ptm(self.dilate_mask(sm, dil_factor))
+                tgt.append(d)
+                lp += d
+            lp[lp > 0] = 1
+            tgt.append(1 - lp)
+            lp = self._nearest(lp, hw)
+            return torch.stack(tgt), torch.stack(ori), lp, deepcopy(lp)
+        if draw_mask is None:
+            for sm in tgt_mask_lists:
+                d, s = ptm(self.dilate_mask(sm, dil_factor)), ptm(sm)
+                tgt.append(d if dil_completion else s)
+                fg += s
+                lp += d
+            fg[fg > 0] = 1
+            lp[lp > 0] = 1
+            tgt.append(1 - fg if dil_completion else 1 - lp)
+            lp = self._nearest(lp * (1 - fg), hw)
+            return torch.stack(tgt), torch.stack(ori), lp, (deepcopy(lp) if dil_completion else torch.zeros_like(lp))
+        for i, sm in enumerate(tgt_mask_lists):
+            s = ptm(sm)
+            d = ptm(draw_mask[i]) + s
+            d[d > 0] = 1
+            tgt.append(d)
+            fg += s
+            lp += d
+        fg[fg > 0] = 1
+        lp[lp > 0] = 1
+        tgt.append(1 - lp)
+        lp = self._nearest(lp * (1 - fg), hw)
+        return torch.stack(tgt), torch.stack(ori), lp, lp
+
+    # ------------------------------------------------------------------------------------------------------------
+    # task-level API (model.py:1012-1118, 1341-1388, 1640-1804)
+    # ------------------------------------------------------------------------------------------------------------
+    def prepare_controller_ref_mask(self, mask, use_mask_expansion=True):
+        if mask.ndim == 3:
+            mask = mask[:, :, 0]
+        mask = torch.Tensor(mask)
+        if use_mask_expansion:
+            self.controller.obj_mask = mask
+            self.controller.log_mask = True
+        return mask
+
+    @torch.no_grad()
+    def DDIM_inversion_func(self, img, mask, prompt, num_step, start_step=0, ref_img=None, verbose=False):
+        imgs = [img] if ref_img is None else [img, self.resize_img(ref_img, size=[512, 512])]
+        source = torch.from_numpy(np.stack(imgs))                       # uint8 [N,H,W,3]; /127.5-1 happens in the VAE's first kernel
+        mask = self.prepare_controller_ref_mask(mask, False)
+        latents, latents_list = self.invert(source, prompt, guidance_scale=1.0, num_inference_steps=num_step,
+                                            num_actual_inference_steps=num_step - start_step, return_intermediates=True, verbose=verbose)
+        self.controller.reset()
+        return mask.detach().cpu().numpy(), latents_list
+
+    @torch.no_grad()
+    def DDIM_inversion_func_compose(self, img, compose_imgs, prompt, num_step, start_step=0, verbose=False):
+        imgs = [img] + [self.resize_img(r, size=[512, 512]) for r in compose_imgs]
+        source = torch.from_numpy(np.stack(imgs))
+        latents, latents_list = self.invert(source, prompt, guidance_scale=1.0, num_inference_steps=num_step,
+                                            num_actual_inference_steps=num_step - start_step, return_intermediates=True, verbose=verbose)
+        self.controller.reset()
+        return latents_list
+
+    def Details_Preserving_regeneration(self, source_image, inverted_latents, edit_prompt, shifted_mask, ori_mask, draw_mask,
+                                        num_steps=100, start_step=30, end_step=10, eta=1, guidance_scale=7.5, share_attn=True,
+                                        method_type="tca", verbose=False, local_text_edit=True, local_perturbation=True,
+                                        return_intermediates=False, use_auto_draw=False, cons_area=None, use_share_attention=False,
+                                        reduce_inp_artifacts=False, end_scale=0.5):
+        init_code = deepcopy(inverted_latents[-1])
+        full_h, full_w = source_image.shape[:2]
+        fg, shifted_t, ori_t, cfg_m, var_m = self.prepare_various_mask(shifted_mask, ori_mask, draw_mask, full_h, full_w, init_code,
+                                                                       verbose=verbose, use_auto_draw=use_auto_draw, cons_area=cons_area,
+                                                                       reduce_inp_artifacts=reduce_inp_artifacts)
+        cfg_m = self._nearest(cfg_m, (init_code.shape[2], init_code.shape[3]))
+        c = self.controller
+        c.fg_retain_mask, c.fg_retain_mask_st2, c.fg_ref_mask, c.local_edit_region = fg, shifted_t, ori_t, fg
+        c.reset()
+        c.log_mask = False
+        # NB `local_text_edit` is forwarded under the wrong keyword by the reference (blending=, model.py:1692), so the loop's
+        # local_edit_text stays True whatever the caller passed; kept.
+        gen_images, intermediates = self.forward_sampling(
+            prompt=[edit_prompt, ""], refer_latents=inverted_latents[::-1], end_step=end_step, batch_size=2, latents=init_code,
+            guidance_scale=guidance_scale, num_inference_steps=num_steps, num_actual_inference_steps=num_steps - start_step, eta=eta,
+            completion_mask_cfg=cfg_m, local_var_reg=var_m, share_attn=share_attn, method_type=method_type, verbose=verbose,
+            blending=local_text_edit, local_perturbation=local_perturbation, return_intermediates=return_intermediates,
+            use_share_attention=use_share_attention, end_scale=end_scale)
+        c.reset()
+        to_u8 = lambda im: (im.permute(1, 2, 0).detach().cpu().numpy() * 255).astype(np.uint8)
+        return to_u8(gen_images[0]), to_u8(gen_images[1]), intermediates
+
+    def Details_Preserving_regeneration_compose(self, source_image, inverted_latents, edit_prompt_list, ori_mask_lists, tgt_mask_lists,
+                                                draw_mask, num_steps=100, start_step=30, end_step=10, eta=1, guidance_scale=7.5,
+                                                dil_completion=False, appearance_transfer=False, share_attn=True, method_type="tca",
+                                                verbose=False, local_text_edit=True, local_perturbation=True, return_intermediates=False,
+                                                use_share_attention=False, dil_factor=15, end_scale=0.5):
+        init_code = deepcopy(inverted_latents[-1])
+        full_h, full_w = source_image.shape[:2]
+        tgt_t, ori_t, lp, cfg_m = self.prepare_composition_masks(ori_mask_lists, tgt_mask_lists, full_h, full_w, init_code,
+                                                                 dil_completion=dil_completion, dil_factor=dil_factor, draw_mask=draw_mask,
+                                                                 appearance_transfer=appearance_transfer)
+        c = self.controller
+        c.src_masks, c.tgt_masks = ori_t, tgt_t
+        c.reset()
+        img, intermediates = self.forward_sampling_compose(
+            prompt=edit_prompt_list, refer_latents=inverted_latents[::-1], end_step=end_step, batch_size=init_code.shape[0],
+            latents=init_code, guidance_scale=guidance_scale, num_inference_steps=num_steps,
+            num_actual_inference_steps=num_steps - start_step, eta=eta, local_var_reg=lp, local_edit_text=local_text_edit,
+            cfg_masks_tensor=cfg_m, share_attn=share_attn, method_type=method_type, verbose=verbose,
+            local_perturbation=local_perturbation, return_intermediates=return_intermediates, end_scale=end_scale)
+        c.reset()
+        return (img.permute(1, 2, 0).detach().cpu().numpy() * 255).astype(np.uint8), intermediates
+
+    def Details_Preserving_regeneration_background(self, ori_img, inverted_latents, edit_prompt, ori_mask, num_steps=100, start_step=30,
+                                                   end_step=10, guidance_scale=3.5, eta=1, verbose=False, local_text_edit=True,
+                                                   local_perturbation=True, end_scale=0.5, return_intermediates=False, share_attn=True,
+                                                   method_type="tca", latent_blended=True, blend_range=(0, 40)):
+        init_code = deepcopy(inverted_latents[-1])
+        full_h, full_w = ori_img.shape[:2]
+        mask_t, var_m = self.prepare_mask_bggen(ori_mask, full_h, full_w, init_code)
+        c = self.controller
+        c.fg_retain_mask, c.local_edit_region = mask_t, mask_t
+        c.reset()
+        gen_images, intermediates = self.forward_sampling_background_gen(
+            prompt=[edit_prompt, ""], end_step=end_step, batch_size=2, refer_latents=inverted_latents[::-1], latents=init_code,
+            guidance_scale=guidance_scale, num_inference_steps=num_steps, num_actual_inference_steps=num_steps - start_step, eta=eta,
+            local_cfg_reg=var_m, local_var_reg=var_m, share_attn=share_attn, method_type=method_type, verbose=verbose,
+            local_text_edit=local_text_edit, local_perturbation=local_perturbation, return_intermediates=return_intermediates,
+            end_scale=end_scale, latent_blended=latent_blended, blend_range=blend_range)
+        c.reset()
+        return (gen_images[0].permute(1, 2, 0).detach().cpu().numpy() * 255).astype(np.uint8), intermediates
+
+    _METHODS = ["tca", "ssa", "sdsa", "mmsa", "mmsa_es"]
+
+    def FreeFine_generation(self, ori_img, ori_mask, coarse_input, target_mask, guidance_text, guidance_scale, eta, end_step=10,
+                            num_step=50, start_step=25, share_attn=True, method_type="tca", local_text_edit=True,
+                            local_perturbation=True, verbose=True, return_ori=False, seed=42, draw_mask=None,
+                            return_intermediates=False, use_auto_draw=False, cons_area=None, reduce_inp_artifacts=False, end_scale=0.5):
+        assert method_type in self._METHODS, f"check method type f{method_type}, which is not in {self._METHODS}"
+        seed_everything(seed)
+        ori_mask, target_mask = self.mask_reduce_dim(ori_mask), self.mask_reduce_dim(target_mask)
+        if draw_mask is not None:
+            draw_mask = self.mask_reduce_dim(draw_mask)
+        _, inverted = self.DDIM_inversion_func(img=coarse_input, mask=target_mask, prompt="", num_step=num_step, start_step=start_step,
+                                               ref_img=ori_img, verbose=verbose)
+        edit_img, ref_img, inter = self.Details_Preserving_regeneration(
+            coarse_input, inverted, guidance_text, target_mask, ori_mask, draw_mask, num_steps=num_step, start_step=start_step,
+            end_step=end_step, guidance_scale=guidance_scale, eta=eta, share_attn=share_attn, method_type=method_type, verbose=verbose,
+            local_text_edit=local_text_edit, local_perturbation=local_perturbation, return_intermediates=return_intermediates,
+            cons_area=cons_area, use_auto_draw=use_auto_draw, end_scale=end_scale, reduce_inp_artifacts=reduce_inp_artifacts)
+        self.last_intermediates = inter
+        return (edit_img, ref_img) if return_ori else edit_img
+
+    def FreeFine_background_generation(self, ori_img, ori_mask, guidance_text, guidance_scale, eta, end_step=10, num_step=50,
+                                       start_step=25, share_attn=True, method_type="tca", local_text_edit=True, local_perturbation=True,
+                                       verbose=True, seed=42, return_intermediates=False, end_scale=0.5, latent_blended=False,
+                                       blend_range=(0, 40)):
+        seed_everything(seed)
+        ori_mask = self.mask_reduce_dim(ori_mask)
+        _, inverted = self.DDIM_inversion_func(img=ori_img, mask=ori_mask, prompt="", num_step=num_step, start_step=start_step,
+                                               ref_img=None, verbose=verbose)
+        img, inter = self.Details_Preserving_regeneration_background(
+            ori_img, inverted, guidance_text, ori_mask, num_steps=num_step, start_step=start_step, end_step=end_step,
+            guidance_scale=guidance_scale, eta=eta, share_attn=share_attn, method_type=method_type, verbose=verbose, end_scale=end_scale,
+            local_text_edit=local_text_edit, local_perturbation=local_perturbation, return_intermediates=return_intermediates,
+            latent_blended=latent_blended, blend_range=blend_range)
+        self.last_intermediates = inter
+        return img
+
+    def FreeFine_cross_image_composition(self, img_lists, ori_mask_lists, tgt_mask_lists, coarse_input, guidance_text_list, guidance_scale,
+                                         eta, end_step=10, num_step=50, start_step=25, share_attn=True, method_type="tca",
+                                         local_text_edit=True, local_perturbation=True, verbose=True, seed=42, draw_mask=None,
+                                         return_intermediates=False, use_auto_draw=False, end_scale=0.5, dil_completion=False,
+                                         dil_factor=15, appearance_transfer=False):
+        """model.py:1051-1086.  The reference forwards `use_auto_draw` to a callee without that parameter (TypeError as
+        released); it is dropped here so the entry point works."""
+        assert method_type in self._METHODS, f"check method type f{method_type}, which is not in {self._METHODS}"
+        seed_everything(seed)
+        ori_mask_lists = [self.mask_reduce_dim(m) for m in ori_mask_lists]
+        tgt_mask_lists = [self.mask_reduce_dim(m) for m in tgt_mask_lists]
+        inverted = self.DDIM_inversion_func_compose(img=coarse_input, compose_imgs=img_lists, prompt="", num_step=num_step,
+                                                    start_step=start_step, verbose=verbose)
+        img, inter = self.Details_Preserving_regeneration_compose(
+            coarse_input, inverted, guidance_text_list, ori_mask_lists, tgt_mask_lists, draw_mask, num_steps=num_step, start_step=start_step,
+            end_step=end_step, dil_factor=dil_factor, guidance_scale=guidance_scale, eta=eta, share_attn=share_attn, method_type=method_type,
+            verbose=verbose, dil_completion=dil_completion, local_text_edit=local_text_edit, local_perturbation=local_perturbation,
+            return_intermediates=return_intermediates, end_scale=end_scale, appearance_transfer=appearance_transfer)
+        self.last_intermediates = inter
+        return img
+
+
+class FreeFine:
+    """the reference's thin wrapper (model.py:88-102); its run_* methods are empty there as well."""
+
+    def __init__(self, pretrained_model_path="synthetic:sd21-base", device=None):
+        self.model = FreeFinePipeline.from_pretrained(pretrained_model_path, torch_dtype=torch.float16)
+        self.model.scheduler = DDIMScheduler.from_config(self.model.scheduler.config)
+
+    def run_remove(self):
+        pass
+
+    def run_edit(self):
+        pass
+
+    def run_compose(self):
+        pass

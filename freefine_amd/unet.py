@@ -13,6 +13,8 @@ MI355X-first layout decisions
   * per-step scalars (timestep, context_guidance) live in device memory, so a whole forward can be captured in a hipGraph
     and replayed (capture=True) -- ~700 launches become one graph launch.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -29,7 +31,7 @@ class HipUNet:
         self.in_channels = cfg.in_channels
         self.hook, self.controller = "edit", None
         self._graphs = {}
-        self._text_cache = None
+        self._text_bufs = {}
         self.use_graph = False
         self._pack(state)
 
@@ -143,18 +145,23 @@ class HipUNet:
     # text-side precompute: cross-attention K and V^T for all 16 blocks (constant across the sampling loop)
     # ------------------------------------------------------------------------------------------------------------
     def prepare_text(self, enc):
-        key = (enc.data_ptr(), enc._version, tuple(enc.shape))
-        if self._text_cache is not None and self._text_cache[0] == key:
-            return self._text_cache[1]
+        """K and V^T of every cross-attention block for these text embeddings.  Buffers are static per embedding SHAPE
+        (a captured graph keeps pointing at them); they are recomputed in place when a different tensor arrives."""
+        key = tuple(enc.shape)
+        ent = self._text_bufs.get(key)
+        if ent is not None and ent["ref"]() is enc and ent["version"] == enc._version:
+            return ent["kv"]
         Bt, Sk, Dm = enc.shape
-        x = ops.cast(enc.float().contiguous(), self.dtype) if enc.dtype != self.dtype else enc.contiguous()
+        x = enc.to(self.device)
+        x = ops.cast(x.float().contiguous(), self.dtype) if x.dtype != self.dtype else x.contiguous()
         ld = (Sk + 7) // 8 * 8
+        old = ent["kv"] if ent is not None else [(None, None)] * len(self.transformers)
         kv = []
-        for t in self.transformers:
-            k = ops.linear(x, t.w_k2, None, K=Dm)
-            vt = ops.linear(x, t.w_v2, None, K=Dm, rows_per_batch=Sk, transposed_ld=ld)
+        for t, (ko, vo) in zip(self.transformers, old):
+            k = ops.linear(x, t.w_k2, None, K=Dm, out=ko)
+            vt = ops.linear(x, t.w_v2, None, K=Dm, rows_per_batch=Sk, transposed_ld=ld, out=vo)
             kv.append((k, vt))
-        self._text_cache = (key, kv, enc)
+        self._text_bufs[key] = dict(ref=weakref.ref(enc), version=enc._version, kv=kv)
         return kv
 
     # ------------------------------------------------------------------------------------------------------------
@@ -171,33 +178,62 @@ class HipUNet:
         text_kv = self.prepare_text(enc)
         if not self.use_graph:
             return self._run(sample, text_kv)
-        sig = self._signature(B, sample.shape, enc.shape)
+        # graph mode: plan every attention call first (this also refreshes the controller's static mask vectors and
+        # advances its counters exactly as an eager forward would); the plans' fingerprint is part of the graph key
+        state = (c.cur_att_layer, c.cur_step) if c is not None else None
+        fp = self._plan_all(B, sample.shape[2], sample.shape[3])
+        sig = (B, tuple(sample.shape), tuple(enc.shape), fp)
         g = self._graphs.get(sig)
         if g is None:
-            g = self._capture(sample, text_kv, sig)
-        else:
-            # replay: the controller still has to advance its counters as if every attention call had run
             if c is not None:
-                for _ in range(self.num_attention_calls):
-                    c._tick()
+                c.cur_att_layer, c.cur_step = state
+            g = self._capture(sample, text_kv, sig)
         g["x"].copy_(sample)
         g["graph"].replay()
         return g["out"].clone()
 
-    def _signature(self, B, shape, enc_shape):
+    def _call_list(self, H, W):
+        """(is_cross, place, S, heads) of every attention call in execution order."""
+        cfg = self.cfg
+        n = len(cfg.block_out_channels)
+        out = []
+        h, w = H, W
+        for i in range(n):
+            if cfg.down_has_attn[i]:
+                out += [(x, "down", h * w, cfg.heads[i]) for _ in range(cfg.layers_per_block) for x in (False, True)]
+            if i < n - 1:
+                h, w = (h + 1) // 2, (w + 1) // 2
+        out += [(False, "mid", h * w, cfg.heads[n - 1]), (True, "mid", h * w, cfg.heads[n - 1])]
+        rev_attn = list(reversed(cfg.down_has_attn))
+        for i in range(n):
+            if rev_attn[i]:
+                out += [(x, "up", h * w, cfg.heads[n - 1 - i]) for _ in range(cfg.layers_per_block + 1) for x in (False, True)]
+            if i < n - 1:
+                h, w = 2 * h, 2 * w
+        return out
+
+    def _plan_all(self, B, H, W):
         c = self.controller
         if c is None:
-            return (B, tuple(shape), tuple(enc_shape), None)
-        masks = tuple((id(m), getattr(m, "_version", 0)) for m in (c.fg_retain_mask, c.fg_ref_mask, c.local_edit_region, c.src_masks, c.tgt_masks)
-                      if m is not None)
-        return (B, tuple(shape), tuple(enc_shape), self.hook, c.use_tca, c.use_style_align, c.local_edit, c.method, tuple(c.layer_idx),
-                c.cur_att_layer, c.prompt_length, masks, id(self._text_cache[2]))
+            return None
+        fps = []
+        for is_cross, place, S, heads in self._call_list(H, W):
+            plan = c.plan(self.hook, is_cross, place, B, S, heads, self.device)
+            if plan["passes"] is None:
+                fps.append(0)
+                continue
+            rows = tuple(tuple(None if e is None else (e.q_row, e.kv_row, e.w_const, e.w_slope, e.flags,
+                                                       0 if e.wq is None else e.wq.data_ptr(),
+                                                       0 if e.kmask is None else e.kmask.data_ptr(),
+                                                       0 if e.qsel is None else e.qsel.data_ptr()) for e in r) for r in plan["passes"])
+            fps.append((plan["kind"], plan["needs_cg"], rows))
+        return (self.hook, tuple(fps))
 
     def _capture(self, sample, text_kv, sig):
         c = self.controller
         state = (c.cur_att_layer, c.cur_step) if c is not None else None
         x_static = sample.clone()
-        # warm-up outside capture (lazy module loading, LDS opt-ins), then restore the controller's counters
+        # warm-up outside capture (lazy module loading, LDS opt-ins, first upload of mask vectors), counters restored after
         self._run(x_static, text_kv)
         if c is not None:
             c.cur_att_layer, c.cur_step = state

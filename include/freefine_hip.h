@@ -33,8 +33,8 @@ const char* ffn_last_error(void);
 int ffn_device_info(int device, char* name, int name_len);
 
 /* ---- implicit GEMM: Linear / 1x1 conv (dense A) and 3x3 conv (im2col gather) ------------------------------
- * out[m,n] = epi( alpha * sum_k A(m,k) W[n,k] ), W is [N][Kpad] (K contiguous, zero padded to Kpad, Kpad % kstage == 0
- * with kstage = 32 (f32) / 64 (bf16)).
+ * out[m,n] = epi( alpha * sum_k A(m,k) W[n,k] ), W is [N][Kpad]: K contiguous, Kpad = row stride of W (>= K, multiple of
+ * the 16-byte chunk: 4 f32 / 8 bf16); columns >= K are never read, so an activation can serve as W (attention-as-GEMM).
  * Replaces: diffusers ResnetBlock2D/Downsample2D/Upsample2D/Linear modules reached from override_forward
  * (src/utils/attention.py:105-214) and to_q/to_k/to_v/to_out in the hooked Attention.forward (attention.py:372-407). */
 enum {
