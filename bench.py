@@ -1,0 +1,218 @@
+"""bench.py -- the FreeFine hot path on MI355X, measured on BASELINE.json's metric and config.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = ONE edited image = one full `FreeFine_generation` call at 512x512 on SD-2.1-base topology (865.9 M parameter
+UNet + SD VAE, seeded synthetic weights: no checkpoints exist offline), N=50 DDIM schedule run in full (start_step=0:
+50 inversion forwards at UNet batch 2 + 50 guided-denoising forwards at UNet batch 4 with TCA attention injection in blocks
+10-15, local cross-attention, masked CFG, masked DDPM step) + VAE encode/decode, inputs resident on the GPU box's host
+(images are 768 KB; the PCIe upload is inside the timed region, as it is for the reference).
+Rank r edits its own images (weak scaling: independent units, no data-path collective); value = images of
+all ranks / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel (largest total time of an eagerly executed, HIP-event-timed image in this very process):
+                achieved = algorithmic FLOPs per launch / average launch duration; peak = dense MFMA peak of the dtype.
+  cpu_baseline  the CPU oracle (oracle/, "port") timed on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+F_UNET = 0.804e12      # algorithmic FLOPs, one sample, one UNet forward @64x64
+F_TCA = 72.5e9         # one extra attention pass in blocks 10-15 per sample-forward
+F_VAE = 7.26e12        # 2 encodes + 2 decodes @512^2
+
+
+def synth_inputs(idx=0):
+    """SURVEY 8(d) synthetic inputs: seeded images, rectangular masks (non-wrapping draw-mask branch)."""
+    ori_img = np.random.default_rng(2 * idx).integers(0, 256, (512, 512, 3), dtype=np.uint8)
+    coarse = np.random.default_rng(2 * idx + 1).integers(0, 256, (512, 512, 3), dtype=np.uint8)
+    ori_mask = np.zeros((512, 512), np.uint8)
+    ori_mask[200:300, 100:200] = 1
+    tgt_mask = np.zeros((512, 512), np.uint8)
+    tgt_mask[200:300, 160:260] = 255
+    draw = np.zeros((512, 512), np.uint8)
+    draw[190:310, 150:270] = 1
+    return ori_img, ori_mask, coarse, tgt_mask, draw
+
+
+def build_model(args, device, rank, world):
+    from freefine_amd.attention import Attention_Modulator, register_attention_control
+    from freefine_amd.config import UNetConfig, VAEConfig
+    from freefine_amd.pipeline import FreeFinePipeline
+    from freefine_amd.scheduler import DDIMScheduler
+    from freefine_amd.text import ByteTokenizer, SyntheticTextEncoder
+    from freefine_amd.weights import synthetic_state, unet_param_shapes, vae_param_shapes
+    ucfg, vcfg = UNetConfig.preset(args.model), VAEConfig.preset(args.vae)
+    if world > 1:
+        from freefine_amd import dist as FD
+        ust = FD.broadcast_state(synthetic_state(unet_param_shapes(ucfg), 0) if rank == 0 else None, unet_param_shapes(ucfg), device)
+        vst = FD.broadcast_state(synthetic_state(vae_param_shapes(vcfg), 1) if rank == 0 else None, vae_param_shapes(vcfg), device)
+    else:
+        ust, vst = synthetic_state(unet_param_shapes(ucfg), 0), synthetic_state(vae_param_shapes(vcfg), 1)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = FreeFinePipeline.from_state(ucfg, ust, vcfg, vst, ByteTokenizer(), SyntheticTextEncoder(ucfg.cross_attention_dim), None, dtype, device)
+    model.scheduler = DDIMScheduler.from_config(model.scheduler.config)
+    controller = Attention_Modulator(start_layer=10)
+    model.controller = controller
+    register_attention_control(model, controller)
+    model.modify_unet_forward()
+    model.unet.use_graph = not args.no_graph
+    return model
+
+
+def edit_once(model, args, idx):
+    ori_img, ori_mask, coarse, tgt_mask, draw = synth_inputs(idx)
+    return model.FreeFine_generation(ori_img, ori_mask, coarse, tgt_mask, "a photo of a cup", 7.5, 1.0, end_step=args.num_step,
+                                     num_step=args.num_step, start_step=args.start_step, method_type="tca", verbose=True, seed=42,
+                                     draw_mask=draw, end_scale=0.0)
+
+
+def roofline_leg(model, args):
+    """one image executed eagerly with a HIP event pair around every launch (ops.profile_*), on the launch stream."""
+    from freefine_amd import ops
+    was = model.unet.use_graph
+    model.unet.use_graph = False
+    ops.profile_begin()
+    edit_once(model, args, 0)
+    prof = ops.profile_end()
+    model.unet.use_graph = was
+    name, d = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+    avg_ms = d["total_ms"] / d["calls"]
+    achieved = d["flops"] / d["calls"] / (avg_ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[args.dtype]
+    total_ms = sum(v["total_ms"] for v in prof.values())
+    table = sorted(((k, v["calls"], v["total_ms"], v["flops"] / max(v["total_ms"], 1e-9) / 1e9) for k, v in prof.items()), key=lambda t: -t[2])
+    return dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
+                traffic=None, launches=d["calls"], avg_launch_us=round(avg_ms * 1e3, 2),
+                share_of_timed_kernels=round(d["total_ms"] / total_ms, 3)), table
+
+
+def cpu_baseline_leg(args):
+    """the oracle (CPU restatement, 'port') on this host: one inversion forward (B=2) + one guided forward (B=4, TCA +
+    local cross-attention) of the same SD-2.1 topology at 64x64, then extrapolated to the schedule; VAE bracket timed once."""
+    from oracle import attention_modulation as OA
+    from oracle import sd_unet, sd_vae
+    torch.set_num_threads(min(os.cpu_count(), args.cpu_threads))    # torch's CPU convs stop scaling (and regress) far below 256 threads
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        net = sd_unet.init_unet(sd_unet.unet_config(args.model), seed=0, perturb_norms=False)
+        D = net.cfg.cross_attention_dim
+        g = torch.Generator().manual_seed(0)
+        x2, e2 = torch.randn(2, 4, 64, 64, generator=g), torch.randn(2, 77, D, generator=g)
+        t0 = time.time()
+        net(x2, torch.tensor(481), e2)
+        t_inv = time.time() - t0
+        mod = OA.Modulator("edit", 32)
+        net.set_modulator(mod)
+        _, om, _, tm, _ = synth_inputs(0)
+        mod.use_tca, mod.method, mod.layer_idx, mod.local_edit, mod.context_guidance = True, "tca", list(range(10, 16)), True, 0.5
+        mod.fg_ref_mask, mod.fg_retain_mask, mod.local_edit_region = torch.tensor(om), torch.tensor(tm), torch.tensor(tm)
+        x4, e4 = torch.randn(4, 4, 64, 64, generator=g), torch.randn(4, 77, D, generator=g)
+        t0 = time.time()
+        net(x4, torch.tensor(481), e4)
+        t_den = time.time() - t0
+        t_vae = 0.0
+        if args.vae == "sd" and not args.cpu_skip_vae:
+            vae = sd_vae.init_vae(sd_vae.vae_config("sd"), seed=1, perturb_norms=False)
+            img = torch.randn(1, 3, 512, 512, generator=g)
+            t0 = time.time()
+            z = vae.encode_mean(img)
+            vae.decode(z)
+            t_vae = 2 * (time.time() - t0)     # two images are encoded and decoded per edit
+    n = args.num_step - args.start_step
+    per_image = n * (t_inv + t_den) + t_vae
+    return dict(value=round(1.0 / per_image, 6), unit="images/s", cores=cores, kind="port",
+                sample=f"1 inversion UNet forward B=2 ({t_inv:.2f}s) + 1 guided forward B=4 with TCA ({t_den:.2f}s) at 64x64, x{n} steps; "
+                       f"VAE encode+decode @512^2 once x2 ({t_vae:.2f}s); torch fp32, {cores} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--model", default="sd21-base")
+    ap.add_argument("--vae", default="sd")
+    ap.add_argument("--num-step", dest="num_step", type=int, default=50)
+    ap.add_argument("--start-step", dest="start_step", type=int, default=0)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-skip-vae", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=32)
+    args = ap.parse_args()
+
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    device = torch.device(f"cuda:{local}")
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    from freefine_amd import _lib
+    _lib.load()   # no fallback: fail loudly if the HIP extension is missing
+    model = build_model(args, device, rank, world)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        edit_once(model, args, rank * 1000 + i)
+    barrier()
+    t0 = time.time()
+    for i in range(args.steps):
+        out = edit_once(model, args, rank * 1000 + 100 + i)
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    assert out.shape == (512, 512, 3) and out.dtype == np.uint8
+
+    if rank == 0:
+        n = args.num_step - args.start_step
+        f_img = n * (2 * F_UNET + 4 * F_UNET + 4 * F_TCA) + F_VAE
+        value = world * args.steps / dt
+        line = {
+            "metric": "edited images/sec/GPU @512px 50-step DDIM", "value": round(value, 4), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"SD-2.1-base topology ({args.model}) 512x512 FreeFine_generation edit, {args.num_step}-step DDIM schedule "
+                                   f"(start_step={args.start_step}: {n} inversion forwards B=2 + {n} guided forwards B=4, TCA blocks 10-15, "
+                                   "masked CFG 7.5, eta=1) + VAE bracket; seeded random weights",
+                       "images_per_gpu_per_step": 1, "unet_batch": 4, "hip_graph": not args.no_graph,
+                       "algorithmic_tflop_per_image": round(f_img / 1e12, 1),
+                       "whole_path_tflops_per_gpu": round(f_img * value / world / 1e12, 1),
+                       "whole_path_frac_of_mfma_peak": round(f_img * value / world / 1e12 / PEAK_TFLOPS[args.dtype], 4)},
+        }
+        if not args.no_roofline:
+            line["roofline"], table = roofline_leg(model, args)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_kernel_table.txt"), "w") as f:
+                f.write("kernel\tcalls\ttotal_ms\talgorithmic_TFLOP/s\n")
+                for k, c, ms, gf in table:
+                    f.write(f"{k}\t{c}\t{ms:.3f}\t{gf:.1f}\n")
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline_leg(args)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

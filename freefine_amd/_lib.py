@@ -71,6 +71,8 @@ SYMBOLS = {
     "ffn_device_info": (_i, [_i, C.c_char_p, _i]),
     "ffn_igemm": (_i, [_vp, _i, C.POINTER(IgemmDesc)]),
     "ffn_attn": (_i, [_vp, _i, C.POINTER(AttnDesc)]),
+    "ffn_igemm_variant": (_i, [C.POINTER(IgemmDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ffn_attn_variant": (_i, [_i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ffn_gn_nchunk": (_i, [_i]),
     "ffn_gn_stats": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "ffn_gn_apply": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
@@ -104,6 +106,7 @@ def load():
             raise FreeFineHipError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+        import torch  # noqa: F401  -- load torch's HIP runtime FIRST so this library binds to the same libamdhip64 instance
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -24,6 +24,12 @@ static int check_launch(const char* what) {
     if (e != hipSuccess) return fail(FFN_EHIP, "%s: %s", what, hipGetErrorString(e));
     return FFN_OK;
 }
+// a stale error left behind by an unrelated earlier HIP call (e.g. a tool's probe) must not be blamed on our launch
+#define LAUNCH(...)                  \
+    do {                             \
+        (void)hipGetLastError();     \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
 #define REQUIRE(cond, ...) \
     do {                   \
         if (!(cond)) return fail(FFN_EINVAL, __VA_ARGS__); \
@@ -71,20 +77,41 @@ static int launch_igemm(hipStream_t s, const ffn_igemm_desc& d) {
         lds_set = true;
     }
     const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
-    hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(256), lds, s, d);
+    LAUNCH(kern, dim3(ntm * ntn), dim3(256), lds, s, d);
     return check_launch("igemm");
 }
+static void igemm_tile_for(const ffn_igemm_desc& d, int* bm, int* bn);
 template <typename T, int AMODE, bool SWAP>
 static int dispatch_igemm_tile(hipStream_t s, const ffn_igemm_desc& d) {
     // pick the largest tile that still gives the chip >= ~1 wave of workgroups (256 CUs, 2 workgroups/CU)
-    const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
-    const long t12864 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64);
-    const bool geglu = d.flags & FFN_IG_GEGLU;
-    if (d.N > 64 && (t128 >= 384 || (d.N % 128 == 0 && t128 >= 256))) return launch_igemm<T, 128, 128, AMODE, SWAP>(s, d);
-    if (t12864 >= 256 || d.M >= 4096) return launch_igemm<T, 128, 64, AMODE, SWAP>(s, d);
-    (void)geglu;
+    int bm, bn;
+    igemm_tile_for(d, &bm, &bn);
+    if (bm == 128 && bn == 128) return launch_igemm<T, 128, 128, AMODE, SWAP>(s, d);
+    if (bm == 128) return launch_igemm<T, 128, 64, AMODE, SWAP>(s, d);
     return launch_igemm<T, 64, 64, AMODE, SWAP>(s, d);
 }
+static void igemm_tile_for(const ffn_igemm_desc& d, int* bm, int* bn) {
+    const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+    const long t12864 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64);
+    if (d.N > 64 && (t128 >= 384 || (d.N % 128 == 0 && t128 >= 256))) { *bm = 128; *bn = 128; }
+    else if (t12864 >= 256 || d.M >= 4096) { *bm = 128; *bn = 64; }
+    else { *bm = 64; *bn = 64; }
+}
+extern "C" int ffn_igemm_variant(const ffn_igemm_desc* d, int* bm, int* bn) {
+    REQUIRE(d && bm && bn, "igemm_variant: null argument");
+    igemm_tile_for(*d, bm, bn);
+    return FFN_OK;
+}
+extern "C" int ffn_attn_variant(int dtype, int D, int* dp, int* qf) {
+    REQUIRE(dp && qf, "attn_variant: null argument");
+    if (dtype == FFN_F32) {
+        if (D <= 48) { *dp = 48; *qf = 2; } else if (D <= 64) { *dp = 64; *qf = 2; } else if (D <= 80) { *dp = 80; *qf = 2; } else { *dp = 160; *qf = 1; }
+    } else {
+        if (D <= 64) { *dp = 64; *qf = 2; } else if (D <= 96) { *dp = 96; *qf = 2; } else { *dp = 160; *qf = 1; }
+    }
+    return FFN_OK;
+}
+
 template <typename T>
 static int dispatch_igemm(hipStream_t s, const ffn_igemm_desc& d) {
     const bool tr = d.flags & FFN_IG_OUT_TRANSPOSED;
@@ -144,7 +171,7 @@ static int launch_attn(hipStream_t s, const ffn_attn_desc& d) {
         lds_set = true;
     }
     dim3 grid((d.S + 64 * QF - 1) / (64 * QF), d.heads, d.Bo);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, d);
+    LAUNCH(kern, grid, dim3(256), lds, s, d);
     return check_launch("attn");
 }
 extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
@@ -192,10 +219,10 @@ extern "C" int ffn_gn_stats(void* stream, int dtype, const void* x, const float*
     const int ppc = (HW + nchunk - 1) / nchunk;
     const int lds = 2 * C * (int)sizeof(float);
     if (dtype == FFN_F32)
-        hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nchunk, B), dim3(256), lds, s, (const float*)x, partial_ws, HW, C, ppc);
+        LAUNCH(gn_partial_kernel<float>, dim3(nchunk, B), dim3(256), lds, s, (const float*)x, partial_ws, HW, C, ppc);
     else
-        hipLaunchKernelGGL(gn_partial_kernel<bf16>, dim3(nchunk, B), dim3(256), lds, s, (const bf16*)x, partial_ws, HW, C, ppc);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, s, partial_ws, gamma, beta, scale, shift, HW, C, G, nchunk, eps);
+        LAUNCH(gn_partial_kernel<bf16>, dim3(nchunk, B), dim3(256), lds, s, (const bf16*)x, partial_ws, HW, C, ppc);
+    LAUNCH(gn_finalize_kernel, dim3(G, B), dim3(64), 0, s, partial_ws, gamma, beta, scale, shift, HW, C, G, nchunk, eps);
     return check_launch("gn_stats");
 }
 extern "C" int ffn_gn_apply(void* stream, int dtype, const void* x, void* y, const float* scale, const float* shift, int B, int HW,
@@ -207,11 +234,11 @@ extern "C" int ffn_gn_apply(void* stream, int dtype, const void* x, void* y, con
     const long nch = (long)B * HW * (C / epc);
     const int grid = grid_for(nch);
     if (dtype == FFN_F32) {
-        if (silu) hipLaunchKernelGGL((gn_apply_kernel<float, true>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, nch, HW, C);
-        else hipLaunchKernelGGL((gn_apply_kernel<float, false>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, nch, HW, C);
+        if (silu) LAUNCH((gn_apply_kernel<float, true>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, nch, HW, C);
+        else LAUNCH((gn_apply_kernel<float, false>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, nch, HW, C);
     } else {
-        if (silu) hipLaunchKernelGGL((gn_apply_kernel<bf16, true>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, scale, shift, nch, HW, C);
-        else hipLaunchKernelGGL((gn_apply_kernel<bf16, false>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, scale, shift, nch, HW, C);
+        if (silu) LAUNCH((gn_apply_kernel<bf16, true>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, scale, shift, nch, HW, C);
+        else LAUNCH((gn_apply_kernel<bf16, false>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, scale, shift, nch, HW, C);
     }
     return check_launch("gn_apply");
 }
@@ -225,11 +252,11 @@ extern "C" int ffn_layernorm(void* stream, int dtype, const void* x, void* y, co
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int grid = (M + 3) / 4;
     if (dtype == FFN_F32) {
-        if (cch <= 128) hipLaunchKernelGGL((layernorm_kernel<float, 2>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, gamma, beta, M, C, eps);
-        else hipLaunchKernelGGL((layernorm_kernel<float, 6>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, gamma, beta, M, C, eps);
+        if (cch <= 128) LAUNCH((layernorm_kernel<float, 2>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, gamma, beta, M, C, eps);
+        else LAUNCH((layernorm_kernel<float, 6>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, gamma, beta, M, C, eps);
     } else {
-        if (cch <= 128) hipLaunchKernelGGL((layernorm_kernel<bf16, 2>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, gamma, beta, M, C, eps);
-        else hipLaunchKernelGGL((layernorm_kernel<bf16, 6>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, gamma, beta, M, C, eps);
+        if (cch <= 128) LAUNCH((layernorm_kernel<bf16, 2>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, gamma, beta, M, C, eps);
+        else LAUNCH((layernorm_kernel<bf16, 6>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, gamma, beta, M, C, eps);
     }
     return check_launch("layernorm");
 }
@@ -237,8 +264,8 @@ extern "C" int ffn_softmax_rows(void* stream, int dtype, const void* x, void* y,
     REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "softmax_rows: bad dtype");
     REQUIRE(x && y && M > 0 && N > 0, "softmax_rows: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == FFN_F32) hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (const float*)x, (float*)y, N, scale);
-    else hipLaunchKernelGGL(softmax_rows_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, s, (const bf16*)x, (bf16*)y, N, scale);
+    if (dtype == FFN_F32) LAUNCH(softmax_rows_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (const float*)x, (float*)y, N, scale);
+    else LAUNCH(softmax_rows_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, s, (const bf16*)x, (bf16*)y, N, scale);
     return check_launch("softmax_rows");
 }
 
@@ -246,19 +273,19 @@ extern "C" int ffn_softmax_rows(void* stream, int dtype, const void* x, void* y,
 extern "C" int ffn_cfg_masked(void* stream, const float* eps_u, const float* eps_c, const float* mask, float cfg, float* eps, long n,
                               int HW) {
     REQUIRE(eps_u && eps_c && eps && n > 0 && HW > 0, "cfg_masked: bad arguments");
-    hipLaunchKernelGGL(cfg_masked_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), eps_u, eps_c, mask, cfg, eps, n, HW);
+    LAUNCH(cfg_masked_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), eps_u, eps_c, mask, cfg, eps, n, HW);
     return check_launch("cfg_masked");
 }
 extern "C" int ffn_ddim_inv_step(void* stream, const float* eps, const float* x, float c_bt, float c_at, float c_an, float c_bn,
                                  float* x_next, float* pred_x0, long n) {
     REQUIRE(eps && x && x_next && n > 0, "ddim_inv_step: bad arguments");
-    hipLaunchKernelGGL(ddim_inv_step_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), eps, x, c_bt, c_at, c_an, c_bn, x_next, pred_x0, n);
+    LAUNCH(ddim_inv_step_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), eps, x, c_bt, c_at, c_an, c_bn, x_next, pred_x0, n);
     return check_launch("ddim_inv_step");
 }
 extern "C" int ffn_ddim_ctrl_step(void* stream, const ffn_ctrl_step_desc* d) {
     REQUIRE(d && d->eps && d->x && d->x_prev && d->m && d->om, "ddim_ctrl_step: null pointer");
     REQUIRE(d->rows > 0 && d->rows <= 8 && d->CHW > 0 && d->HW > 0 && d->CHW % d->HW == 0, "ddim_ctrl_step: bad shape");
-    hipLaunchKernelGGL(ddim_ctrl_step_kernel, dim3(grid_for((long)d->rows * d->CHW)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *d);
+    LAUNCH(ddim_ctrl_step_kernel, dim3(grid_for((long)d->rows * d->CHW)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *d);
     return check_launch("ddim_ctrl_step");
 }
 
@@ -267,14 +294,14 @@ extern "C" int ffn_pack_nchw(void* stream, int dtype, const ffn_pack_desc* d) {
     REQUIRE(d && d->src && d->dst && d->B > 0 && d->B <= 16 && d->CP >= d->Cl, "pack_nchw: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long n = (long)d->B * d->HW * d->CP;
-    if (dtype == FFN_F32) hipLaunchKernelGGL(pack_nchw_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, *d);
-    else if (dtype == FFN_BF16) hipLaunchKernelGGL(pack_nchw_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, s, *d);
+    if (dtype == FFN_F32) LAUNCH(pack_nchw_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, *d);
+    else if (dtype == FFN_BF16) LAUNCH(pack_nchw_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, s, *d);
     else return fail(FFN_EINVAL, "pack_nchw: bad dtype");
     return check_launch("pack_nchw");
 }
 extern "C" int ffn_nhwc_to_nchw_f32(void* stream, const float* src, float* dst, int B, int HW, int C, int ld) {
     REQUIRE(src && dst && B > 0 && HW > 0 && C > 0 && ld >= C, "nhwc_to_nchw_f32: bad arguments");
-    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(grid_for((long)B * HW * C)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, B, HW, C, ld);
+    LAUNCH(nhwc_to_nchw_f32_kernel, dim3(grid_for((long)B * HW * C)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, B, HW, C, ld);
     return check_launch("nhwc_to_nchw_f32");
 }
 extern "C" int ffn_concat(void* stream, int dtype, const void* a, const void* b, void* out, long rows, int C1, int C2) {
@@ -283,16 +310,16 @@ extern "C" int ffn_concat(void* stream, int dtype, const void* a, const void* b,
     REQUIRE(a && b && out && C1 % epc == 0 && C2 % epc == 0 && aligned16(a) && aligned16(b) && aligned16(out), "concat: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long n = rows * ((C1 + C2) / epc);
-    if (dtype == FFN_F32) hipLaunchKernelGGL(concat_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)out, rows, C1, C2);
-    else hipLaunchKernelGGL(concat_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16*)a, (const bf16*)b, (bf16*)out, rows, C1, C2);
+    if (dtype == FFN_F32) LAUNCH(concat_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)out, rows, C1, C2);
+    else LAUNCH(concat_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16*)a, (const bf16*)b, (bf16*)out, rows, C1, C2);
     return check_launch("concat");
 }
 extern "C" int ffn_timestep_embed(void* stream, int dtype, const float* t_dev, const float* freq, void* out, int B, int half, int flip) {
     REQUIRE(t_dev && freq && out && B > 0 && half > 0, "timestep_embed: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int n = B * 2 * half;
-    if (dtype == FFN_F32) hipLaunchKernelGGL(timestep_embed_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, t_dev, freq, (float*)out, B, half, flip);
-    else if (dtype == FFN_BF16) hipLaunchKernelGGL(timestep_embed_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, s, t_dev, freq, (bf16*)out, B, half, flip);
+    if (dtype == FFN_F32) LAUNCH(timestep_embed_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, t_dev, freq, (float*)out, B, half, flip);
+    else if (dtype == FFN_BF16) LAUNCH(timestep_embed_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, s, t_dev, freq, (bf16*)out, B, half, flip);
     else return fail(FFN_EINVAL, "timestep_embed: bad dtype");
     return check_launch("timestep_embed");
 }
@@ -300,8 +327,8 @@ extern "C" int ffn_transpose(void* stream, int dtype, const void* src, void* dst
     REQUIRE(src && dst && B > 0 && R > 0 && C > 0, "transpose: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((C + 31) / 32, (R + 31) / 32, B);
-    if (dtype == FFN_F32) hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (float*)dst, R, C, ld_src, ld_dst);
-    else if (dtype == FFN_BF16) hipLaunchKernelGGL(transpose_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src, (bf16*)dst, R, C, ld_src, ld_dst);
+    if (dtype == FFN_F32) LAUNCH(transpose_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (float*)dst, R, C, ld_src, ld_dst);
+    else if (dtype == FFN_BF16) LAUNCH(transpose_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src, (bf16*)dst, R, C, ld_src, ld_dst);
     else return fail(FFN_EINVAL, "transpose: bad dtype");
     return check_launch("transpose");
 }
@@ -309,10 +336,10 @@ extern "C" int ffn_cast(void* stream, int src_dtype, int dst_dtype, const void* 
     REQUIRE(src && dst && n > 0, "cast: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int grid = grid_for(n);
-    if (src_dtype == FFN_F32 && dst_dtype == FFN_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(grid), dim3(256), 0, s, (const float*)src, (bf16*)dst, n);
-    else if (src_dtype == FFN_BF16 && dst_dtype == FFN_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(grid), dim3(256), 0, s, (const bf16*)src, (float*)dst, n);
-    else if (src_dtype == FFN_F32 && dst_dtype == FFN_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n);
-    else if (src_dtype == FFN_BF16 && dst_dtype == FFN_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)src, (bf16*)dst, n);
+    if (src_dtype == FFN_F32 && dst_dtype == FFN_BF16) LAUNCH((cast_kernel<float, bf16>), dim3(grid), dim3(256), 0, s, (const float*)src, (bf16*)dst, n);
+    else if (src_dtype == FFN_BF16 && dst_dtype == FFN_F32) LAUNCH((cast_kernel<bf16, float>), dim3(grid), dim3(256), 0, s, (const bf16*)src, (float*)dst, n);
+    else if (src_dtype == FFN_F32 && dst_dtype == FFN_F32) LAUNCH((cast_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n);
+    else if (src_dtype == FFN_BF16 && dst_dtype == FFN_BF16) LAUNCH((cast_kernel<bf16, bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)src, (bf16*)dst, n);
     else return fail(FFN_EINVAL, "cast: bad dtypes %d -> %d", src_dtype, dst_dtype);
     return check_launch("cast");
 }
@@ -320,8 +347,8 @@ extern "C" int ffn_image_to_nhwc(void* stream, int dtype, const uint8_t* img, vo
     REQUIRE(img && dst && npix > 0 && CP >= 3, "image_to_nhwc: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int grid = grid_for(npix * CP);
-    if (dtype == FFN_F32) hipLaunchKernelGGL(image_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, s, img, (float*)dst, npix, CP);
-    else if (dtype == FFN_BF16) hipLaunchKernelGGL(image_to_nhwc_kernel<bf16>, dim3(grid), dim3(256), 0, s, img, (bf16*)dst, npix, CP);
+    if (dtype == FFN_F32) LAUNCH(image_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, s, img, (float*)dst, npix, CP);
+    else if (dtype == FFN_BF16) LAUNCH(image_to_nhwc_kernel<bf16>, dim3(grid), dim3(256), 0, s, img, (bf16*)dst, npix, CP);
     else return fail(FFN_EINVAL, "image_to_nhwc: bad dtype");
     return check_launch("image_to_nhwc");
 }
@@ -329,8 +356,8 @@ extern "C" int ffn_nhwc_to_image(void* stream, int dtype, const void* src, float
     REQUIRE(src && dst && B > 0 && HW > 0 && ld >= 3, "nhwc_to_image: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int grid = grid_for((long)B * 3 * HW);
-    if (dtype == FFN_F32) hipLaunchKernelGGL(nhwc_to_image_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, dst, B, HW, ld);
-    else if (dtype == FFN_BF16) hipLaunchKernelGGL(nhwc_to_image_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)src, dst, B, HW, ld);
+    if (dtype == FFN_F32) LAUNCH(nhwc_to_image_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, dst, B, HW, ld);
+    else if (dtype == FFN_BF16) LAUNCH(nhwc_to_image_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)src, dst, B, HW, ld);
     else return fail(FFN_EINVAL, "nhwc_to_image: bad dtype");
     return check_launch("nhwc_to_image");
 }

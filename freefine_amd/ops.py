@@ -35,6 +35,54 @@ def _p(t):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg)
+# ---------------------------------------------------------------------------------------------------------------
+_PROF = None
+
+
+def profile_begin():
+    global _PROF
+    _PROF = []
+
+
+def profile_end():
+    """-> {kernel name: dict(calls, total_ms, flops, bytes)}; kernel names spelled like rocprofv3's kernel trace."""
+    global _PROF
+    rec, _PROF = _PROF, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, flops, nbytes, s, e in rec:
+        d = out.setdefault(name, dict(calls=0, total_ms=0.0, flops=0.0, bytes=0.0))
+        d["calls"] += 1
+        d["total_ms"] += s.elapsed_time(e)
+        d["flops"] += flops
+        d["bytes"] += nbytes
+    return out
+
+
+def _timed(name, flops, nbytes, fn):
+    if _PROF is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    rc = fn()
+    e.record()
+    _PROF.append((name, flops, nbytes, s, e))
+    return rc
+
+
+def _tname(t):
+    return "float" if t.dtype == torch.float32 else "bf16"
+
+
+def _igemm_name(lib, x, d):
+    bm, bn = CT.c_int(), CT.c_int()
+    lib.ffn_igemm_variant(CT.byref(d), CT.byref(bm), CT.byref(bn))
+    swap = "false" if (d.flags & L.IG_OUT_TRANSPOSED) else "true"
+    return f"void igemm_kernel<{_tname(x)}, {bm.value}, {bn.value}, {d.conv}, {swap}>(ffn_igemm_desc)"
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # weight packing (host side, once at load time)
 # ---------------------------------------------------------------------------------------------------------------
 def pack_linear(w, dtype):
@@ -107,7 +155,12 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
     d.ldr = residual.shape[-1] if residual is not None else 0
     d.out = out.data_ptr()
     d.flags, d.alpha, d.conv = flags, alpha, 0
-    L.check(lib.ffn_igemm(_stream(), _dt(x), CT.byref(d)), "ffn_igemm")
+    if _PROF is None:
+        L.check(lib.ffn_igemm(_stream(), _dt(x), CT.byref(d)), "ffn_igemm")
+    else:
+        esz = x.element_size()
+        L.check(_timed(_igemm_name(lib, x, d), 2.0 * M * N * K, esz * (M * K + N * K + M * n_out),
+                       lambda: lib.ffn_igemm(_stream(), _dt(x), CT.byref(d))), "ffn_igemm")
     return out
 
 
@@ -134,7 +187,12 @@ def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, ou
     d.Hin, d.Win, d.Cin, d.Hout, d.Wout = Hin, Win, Cin, Hout, Wout
     d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
     d.flags, d.alpha, d.conv = (L.IG_OUT_F32 if out_f32 else 0), 1.0, 1
-    L.check(lib.ffn_igemm(_stream(), _dt(x), CT.byref(d)), "ffn_igemm(conv)")
+    if _PROF is None:
+        L.check(lib.ffn_igemm(_stream(), _dt(x), CT.byref(d)), "ffn_igemm(conv)")
+    else:
+        esz = x.element_size()
+        L.check(_timed(_igemm_name(lib, x, d), 2.0 * d.M * N * d.K, esz * (x.numel() + N * d.K + d.M * N),
+                       lambda: lib.ffn_igemm(_stream(), _dt(x), CT.byref(d))), "ffn_igemm(conv)")
     return out
 
 
@@ -177,7 +235,16 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
                 continue
             e.q_row, e.kv_row, e.w_const, e.w_slope = sp.q_row, sp.kv_row, sp.w_const, sp.w_slope
             e.wq, e.kmask, e.qsel, e.flags = _p(sp.wq), _p(sp.kmask), _p(sp.qsel), sp.flags
-    L.check(lib.ffn_attn(_stream(), _dt(q), CT.byref(d)), "ffn_attn")
+    if _PROF is None:
+        L.check(lib.ffn_attn(_stream(), _dt(q), CT.byref(d)), "ffn_attn")
+    else:
+        nterms = sum(1 for rows in passes for sp in rows if sp is not None and (sp.w_const != 0.0 or sp.w_slope != 0.0))
+        dp, qf = CT.c_int(), CT.c_int()
+        lib.ffn_attn_variant(_dt(q), Dh, CT.byref(dp), CT.byref(qf))
+        esz = q.element_size()
+        L.check(_timed(f"void attn_kernel<{_tname(q)}, {dp.value}, {qf.value}>(ffn_attn_desc)", 4.0 * nterms * S * Sk * Cq,
+                       esz * nterms * (S * Cq + 2 * Sk * Cq) + esz * Bo * S * Cq,
+                       lambda: lib.ffn_attn(_stream(), _dt(q), CT.byref(d))), "ffn_attn")
     return out
 
 

@@ -59,6 +59,8 @@ typedef struct ffn_igemm_desc {
     int conv; /* 0 = dense, 1 = 3x3 conv */
 } ffn_igemm_desc;
 int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
+/* which tile (BM x BN) ffn_igemm dispatches for this problem -- lets a profiler name the kernel instantiation */
+int ffn_igemm_variant(const ffn_igemm_desc* d, int* bm, int* bn);
 
 /* ---- multi-pass masked attention (the FreeFine attention modulation) -----------------------------------------
  * out[b,q,h,:] = sum_p w_p(b) * wq_p[q] * softmax_k(scale*<Q[qrow_p(b),q,h],K[kvrow_p(b),k,h]> + mask_p(q,k)) V[kvrow_p(b),k,h]
@@ -91,6 +93,8 @@ typedef struct ffn_attn_desc {
     ffn_attn_entry e[FFN_ATT_MAXP * FFN_ATT_MAXB]; /* entry (p,b) at p*FFN_ATT_MAXB + b */
 } ffn_attn_desc;
 int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d);
+/* padded head dim / query fragments per wave of the instantiation ffn_attn dispatches for head dim D */
+int ffn_attn_variant(int dtype, int D, int* dp, int* qf);
 
 /* ---- normalisation ------------------------------------------------------------------------------------------- */
 /* GroupNorm statistics -> per-(batch,channel) scale/shift (fp32).  partial_ws: >= B*nchunk*2*C floats where
