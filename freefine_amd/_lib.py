@@ -24,6 +24,7 @@ class IgemmDesc(C.Structure):
         ("Hin", C.c_int), ("Win", C.c_int), ("Cin", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
         ("stride", C.c_int), ("pad", C.c_int), ("upsample", C.c_int),
         ("flags", C.c_int), ("alpha", C.c_float), ("conv", C.c_int),
+        ("splitk", C.c_int), ("ws", C.c_void_p), ("ws_bytes", C.c_long),
     ]
 
 

@@ -67,7 +67,7 @@ extern "C" int ffn_device_info(int device, char* name, int name_len) {
 
 // ---- igemm -------------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int AMODE, bool SWAP>
-static int launch_igemm(hipStream_t s, const ffn_igemm_desc& d) {
+static int launch_igemm(hipStream_t s, const ffn_igemm_desc& d, int splitk) {
     constexpr int lds = 2 * (BM + BN) * 128;
     auto kern = igemm_kernel<T, BM, BN, AMODE, SWAP>;
     static bool lds_set = false;  // one opt-in per instantiation
@@ -77,25 +77,53 @@ static int launch_igemm(hipStream_t s, const ffn_igemm_desc& d) {
         lds_set = true;
     }
     const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
-    LAUNCH(kern, dim3(ntm * ntn), dim3(256), lds, s, d);
-    return check_launch("igemm");
+    LAUNCH(kern, dim3(ntm * ntn, splitk), dim3(256), lds, s, d);
+    int rc = check_launch("igemm");
+    if (rc || splitk == 1) return rc;
+    const long nq = (long)d.M * (d.N / 4);
+    LAUNCH(igemm_splitk_reduce_kernel<T>, dim3(grid_for(nq)), dim3(256), 0, s, d, splitk);
+    return check_launch("igemm_splitk_reduce");
 }
-static void igemm_tile_for(const ffn_igemm_desc& d, int* bm, int* bn);
+static void igemm_plan_for(int dtype, const ffn_igemm_desc& d, int* bm, int* bn, int* splitk);
 template <typename T, int AMODE, bool SWAP>
 static int dispatch_igemm_tile(hipStream_t s, const ffn_igemm_desc& d) {
     // pick the largest tile that still gives the chip >= ~1 wave of workgroups (256 CUs, 2 workgroups/CU)
-    int bm, bn;
-    igemm_tile_for(d, &bm, &bn);
-    if (bm == 128 && bn == 128) return launch_igemm<T, 128, 128, AMODE, SWAP>(s, d);
-    if (bm == 128) return launch_igemm<T, 128, 64, AMODE, SWAP>(s, d);
-    return launch_igemm<T, 64, 64, AMODE, SWAP>(s, d);
+    int bm, bn, sk;
+    igemm_plan_for(sizeof(T) == 4 ? FFN_F32 : FFN_BF16, d, &bm, &bn, &sk);
+    if (bm == 128 && bn == 128) return launch_igemm<T, 128, 128, AMODE, SWAP>(s, d, sk);
+    if (bm == 128) return launch_igemm<T, 128, 64, AMODE, SWAP>(s, d, sk);
+    return launch_igemm<T, 64, 64, AMODE, SWAP>(s, d, sk);
 }
-static void igemm_tile_for(const ffn_igemm_desc& d, int* bm, int* bn) {
+static bool can_split(const ffn_igemm_desc& d) {
+    return d.ws && d.splitk != 1 && !(d.flags & (FFN_IG_GEGLU | FFN_IG_OUT_TRANSPOSED));
+}
+// tile + number of K slices.  Without split-K small-M problems take small tiles to fill the chip; with it they keep the
+// 128x128 tile (operand reuse) and the K loop is cut so that ~2 workgroups per CU exist.
+static void igemm_plan_for(int dtype, const ffn_igemm_desc& d, int* bm, int* bn, int* splitk) {
     const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
     const long t12864 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64);
-    if (d.N > 64 && (t128 >= 384 || (d.N % 128 == 0 && t128 >= 256))) { *bm = 128; *bn = 128; }
+    *splitk = 1;
+    if (can_split(d) && d.N >= 128 && d.M >= 96 && t128 < 256) {
+        *bm = 128; *bn = 128;
+    } else if (d.N > 64 && (t128 >= 384 || (d.N % 128 == 0 && t128 >= 256))) { *bm = 128; *bn = 128; }
     else if (t12864 >= 256 || d.M >= 4096) { *bm = 128; *bn = 64; }
     else { *bm = 64; *bn = 64; }
+    if (can_split(d)) {
+        const int kstage = dtype == FFN_F32 ? 32 : 64;
+        const int nk = (d.K + kstage - 1) / kstage;
+        const long tiles = (long)((d.M + *bm - 1) / *bm) * ((d.N + *bn - 1) / *bn);
+        int s = d.splitk > 1 ? d.splitk : (tiles >= 256 ? 1 : (int)((512 + tiles - 1) / tiles));
+        if (d.splitk <= 1 && s > nk / 6) s = nk / 6;            // keep >= 6 K stages per slice
+        const long per = (long)d.M * d.N * 4;
+        if ((long)s * per > d.ws_bytes) s = (int)(d.ws_bytes / per);
+        if (s > nk) s = nk;
+        if (s < 1) s = 1;
+        *splitk = s;
+    }
+}
+static void igemm_tile_for(const ffn_igemm_desc& d, int* bm, int* bn) {
+    int s;
+    igemm_plan_for(FFN_BF16, d, bm, bn, &s);
 }
 extern "C" int ffn_igemm_variant(const ffn_igemm_desc* d, int* bm, int* bn) {
     REQUIRE(d && bm && bn, "igemm_variant: null argument");
@@ -154,6 +182,8 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
             REQUIRE(!d->residual && !d->rowbias && !(d->flags & (FFN_IG_OUT_F32 | FFN_IG_OUT_SILU)), "igemm: GEGLU epilogue is exclusive");
         }
     }
+    if (d->ws) REQUIRE(aligned16(d->ws) && d->ws_bytes >= 0, "igemm: workspace must be 16-byte aligned");
+    REQUIRE(d->splitk >= 0, "igemm: splitk must be >= 0");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return dtype == FFN_F32 ? dispatch_igemm<float>(s, *d) : dispatch_igemm<bf16>(s, *d);
 }

@@ -127,12 +127,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.K + BKE - 1) / BKE;
-    issue_loads(0);
-    write_lds(0);
+    // split-K: blockIdx.y owns the K stages [kt0, nk); partial sums go to fp32 slabs, ffn's reduce kernel finishes
+    const int nk_all = (p.K + BKE - 1) / BKE;
+    const int spp = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kt0 = blockIdx.y * spp;
+    const int nk = min(nk_all, kt0 + spp);
+    issue_loads(kt0 * BKE);
+    write_lds(kt0 & 1);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) issue_loads((kt + 1) * BKE);
         const char* Ab = As + buf * BM * 128;
@@ -171,6 +175,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const bool out_f32 = p.flags & IG_OUT_F32;
     const bool out_silu = p.flags & IG_OUT_SILU;
 
+    if (SWAP && gridDim.y > 1) {
+        // split-K partial: raw fp32 accumulators to slab blockIdx.y of the workspace
+        float* __restrict__ slab = reinterpret_cast<float*>(p.ws) + (long)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * WM + i * 16 + l15;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + 4 * g;
+                if (m < p.M && n < p.N) {
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    store4(slab + (long)m * p.N + n, v);
+                }
+            }
+        }
+        return;
+    }
     if (SWAP) {
         // lane holds C[m = ..+l15][n = ..+4g+r], r = 0..3: four consecutive columns of one row
         if (p.flags & IG_GEGLU) {
@@ -267,5 +288,40 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                 }
             }
         }
+    }
+}
+
+// split-K finish: out[m, n..n+3] = epilogue(sum_s slab[s][m][n..n+3])  (same epilogue as the SWAP path of igemm_kernel)
+template <typename T>
+__global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmParams p, int splitk) {
+    const long nq = (long)p.M * (p.N / 4);
+    const float* __restrict__ ws = reinterpret_cast<const float*>(p.ws);
+    T* __restrict__ outT = reinterpret_cast<T*>(p.out);
+    float* __restrict__ outF = reinterpret_cast<float*>(p.out);
+    const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nq; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / (p.N / 4)), n = (int)(i % (p.N / 4)) * 4;
+        f32x4 a = *reinterpret_cast<const f32x4*>(ws + (long)m * p.N + n);
+        for (int s = 1; s < splitk; ++s) a += *reinterpret_cast<const f32x4*>(ws + ((long)s * p.M + m) * p.N + n);
+        const int bb = m / p.rows_per_batch;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = a[r] * p.alpha;
+            if (p.bias) x += p.bias[n + r];
+            if (p.rowbias) x += p.rowbias[(long)bb * p.ldrb + n + r];
+            if (p.flags & IG_OUT_SILU) x = silu_exact(x);
+            v[r] = x;
+        }
+        if (res) {
+            float rr[4];
+            load4(res + (long)m * p.ldr + n, rr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rr[r];
+        }
+        if (p.flags & IG_OUT_F32)
+            store4(outF + (long)m * p.ldo + n, v);
+        else
+            store4(outT + (long)m * p.ldo + n, v);
     }
 }

@@ -119,8 +119,19 @@ def pack_geglu(w, b, dtype):
 # ---------------------------------------------------------------------------------------------------------------
 # igemm
 # ---------------------------------------------------------------------------------------------------------------
+_WS = {}
+WS_BYTES = 96 << 20
+
+
+def _workspace(device):
+    """one fp32 scratch buffer per device for split-K partial slabs (stream-ordered reuse: all launches share one stream)"""
+    ws = _WS.get(device)
+    if ws is None:
+        ws = _WS[device] = torch.empty(WS_BYTES // 4, dtype=torch.float32, device=device)
+    return ws
+
 def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, rows_per_batch=None, silu=False,
-           geglu=False, out_f32=False, transposed_ld=None, alpha=1.0):
+           geglu=False, out_f32=False, transposed_ld=None, alpha=1.0, splitk=0):
     """out = x @ w[:, :K]^T (+bias ...).  x: [..., K] contiguous rows (M = prod of leading dims)."""
     lib = L.load()
     K = K if K is not None else x.shape[-1]
@@ -155,6 +166,7 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
     d.ldr = residual.shape[-1] if residual is not None else 0
     d.out = out.data_ptr()
     d.flags, d.alpha, d.conv = flags, alpha, 0
+    d.splitk, d.ws, d.ws_bytes = splitk, _workspace(x.device).data_ptr(), WS_BYTES
     if _PROF is None:
         L.check(lib.ffn_igemm(_stream(), _dt(x), CT.byref(d)), "ffn_igemm")
     else:
@@ -165,7 +177,7 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
 
 
 def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, out=None, residual=None, rowbias=None,
-            rowbias_ld=None, out_f32=False, Hout=None, Wout=None):
+            rowbias_ld=None, out_f32=False, Hout=None, Wout=None, splitk=0):
     """x: [B, Hin*Win, Cin] NHWC; w: packed [Cout, Kpad]; returns [B, Hout*Wout, Cout]."""
     lib = L.load()
     He, We = (Hin * 2, Win * 2) if upsample else (Hin, Win)
@@ -187,6 +199,7 @@ def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, ou
     d.Hin, d.Win, d.Cin, d.Hout, d.Wout = Hin, Win, Cin, Hout, Wout
     d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
     d.flags, d.alpha, d.conv = (L.IG_OUT_F32 if out_f32 else 0), 1.0, 1
+    d.splitk, d.ws, d.ws_bytes = splitk, _workspace(x.device).data_ptr(), WS_BYTES
     if _PROF is None:
         L.check(lib.ffn_igemm(_stream(), _dt(x), CT.byref(d)), "ffn_igemm(conv)")
     else:

@@ -57,6 +57,9 @@ typedef struct ffn_igemm_desc {
     int flags;
     float alpha;
     int conv; /* 0 = dense, 1 = 3x3 conv */
+    int splitk;       /* 0 = let the library choose (needs ws), 1 = never split, k = force k K-slices */
+    void* ws;         /* optional fp32 scratch for split-K partial slabs (>= splitk*M*N*4 bytes) or NULL */
+    long ws_bytes;
 } ffn_igemm_desc;
 int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
 /* which tile (BM x BN) ffn_igemm dispatches for this problem -- lets a profiler name the kernel instantiation */

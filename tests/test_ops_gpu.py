@@ -319,3 +319,28 @@ def test_pack_unpack_temb(gpu, dtype):
     img = torch.randint(0, 256, (1, 8, 8, 3), generator=g, dtype=torch.uint8).to(gpu)
     x = ops.image_to_nhwc(img, 8, dtype)
     assert relerr(x[..., :3], img.reshape(1, 64, 3).float() / 127.5 - 1) < (1e-6 if dtype == torch.float32 else 5e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("splitk", [0, 1, 3, 7])
+def test_splitk_conv_and_linear(gpu, dtype, splitk):
+    """split-K (fp32 partial slabs + reduce kernel with the full epilogue) must agree with the unsplit result."""
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(31)
+    B, H, W, Cin, Cout = 2, 8, 8, 256, 192
+    x = rnd((B, H * W, Cin), dtype, gpu, g)
+    w = rnd((Cout, Cin, 3, 3), dtype, gpu, g, (9 * Cin) ** -0.5)
+    b = torch.randn(Cout, generator=g).to(gpu)
+    rb = torch.randn(B, Cout, generator=g).to(gpu)
+    res = rnd((B, H * W, Cout), dtype, gpu, g)
+    ref = F.conv2d(x.double().reshape(B, H, W, Cin).permute(0, 3, 1, 2), w.double(), b.double(), padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(B, H * W, Cout) + rb.double()[:, None] + res.double()
+    out = ops.conv3x3(x, ops.pack_conv3x3(w, dtype), b, B, H, W, Cin, rowbias=rb, residual=res, splitk=splitk)
+    assert relerr(out, ref) < tol(dtype)
+    M, K, N = 200, 2048, 320
+    a = rnd((M, K), dtype, gpu, g)
+    wl = rnd((N, K), dtype, gpu, g, K ** -0.5)
+    out = ops.linear(a, ops.pack_linear(wl, dtype), b[:N] if N <= Cout else None, silu=True, splitk=splitk)
+    assert relerr(out, F.silu(a.double() @ wl.double().t())) < tol(dtype)
+    out = ops.linear(a, ops.pack_linear(wl, dtype), None, out_f32=True, splitk=splitk)
+    assert out.dtype == torch.float32 and relerr(out, a.double() @ wl.double().t()) < tol(dtype)
