@@ -24,6 +24,8 @@
 // keeps the same query on the lane, so the online-softmax rescale is lane-local as well.  V arrives TRANSPOSED
 // ([Bk, heads*D, ldvt], written that way for free by the to_v projection's epilogue, IG_OUT_TRANSPOSED).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/freefine_hip.h"
 
@@ -33,11 +35,11 @@ enum { ATT_HEAD_RULE = FFN_ATT_HEAD_RULE, ATT_UNIFORM_SEL1 = FFN_ATT_UNIFORM_SEL
 typedef ffn_attn_entry AttnEntry;
 typedef ffn_attn_desc AttnParams;
 
-template <typename T, int DP, int QF>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+template <typename T, int DP, int QF, int KT = 64, int OCC = 1>   // KT = keys per tile, OCC = min waves per SIMD
+__global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
     constexpr int EPC = DT<T>::EPC;
     constexpr int SZ = sizeof(T);
-    constexpr int KT = 64;                      // keys per tile
+    constexpr int NT = KT / 16;                 // 16-key fragments per tile
     constexpr int KROW = DP * SZ + 16;          // K tile row stride (bytes), +16 B pad against bank conflicts
     constexpr int VROW = KT * SZ + 16;          // V^T tile row stride
     constexpr int DCH = DP / EPC;               // 16-byte chunks per K row
@@ -45,11 +47,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     constexpr int FD = DP / 16;                 // d fragments of O^T
     constexpr int KPC = EPC / 4;                // key fragments per PV chunk (f32: 1, bf16: 2)
     constexpr int VCH = KT / EPC;               // 16-byte chunks per V^T row
+    constexpr int NKC = KT * DCH / 256;         // K chunks staged per thread per tile
+    constexpr int NVC = DP * VCH / 256;         // V^T chunks staged per thread per tile
+    constexpr int KBUF = KT * KROW, VBUF = DP * VROW;
     constexpr float NEG = -1e30f;
+    static_assert((KT * DCH) % 256 == 0 && (DP * VCH) % 256 == 0, "tile must split evenly over 256 threads");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem;                 // [KT][KROW]
-    char* Vs = smem + KT * KROW;     // [DP][VROW]
+    char* Ks = smem;                 // [2][KT][KROW]
+    char* Vs = smem + 2 * KBUF;      // [2][DP][VROW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -59,20 +65,38 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     const T* __restrict__ Qg = reinterpret_cast<const T*>(p.q);
     const T* __restrict__ Kg = reinterpret_cast<const T*>(p.k);
     const T* __restrict__ Vg = reinterpret_cast<const T*>(p.vt);
-    const float c_exp = p.scale * 1.44269504088896340736f;
+    const float c_exp = p.scale * 1.44269504088896340736f;   // softmax in base 2: p = exp2(s*c - m)
 
-    f32x4 tot[FD][QF];
+    // multi-pass sums live in LDS between passes (touched once per pass), not in registers: [wave][FD][QF][lane] f32x4
+    f32x4* totl = reinterpret_cast<f32x4*>(smem + 2 * (KBUF + VBUF)) + wave * (FD * QF * 64) + lane;
+    int nactive = 0, nseen = 0;
+    for (int pass = 0; pass < p.npass; ++pass) {
+        const AttnEntry& e0 = p.e[pass * ATT_MAXB + b];
+        nactive += (e0.w_const != 0.f || e0.w_slope != 0.f) ? 1 : 0;
+    }
+    T* __restrict__ Og = reinterpret_cast<T*>(p.out);
+    if (nactive == 0) {   // nothing contributes to this output row: zeros
 #pragma unroll
-    for (int i = 0; i < FD; ++i)
+        for (int f = 0; f < QF; ++f) {
+            const int q = q0 + f * 16 + l15;
 #pragma unroll
-        for (int j = 0; j < QF; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < FD; ++i) {
+                const int d = i * 16 + 4 * g;
+                float z[4] = {0.f, 0.f, 0.f, 0.f};
+                if (q < p.S && d < D) store4(Og + ((long)b * p.S + q) * p.ldo + head * D + d, z);
+            }
+        }
+        return;
+    }
+
+    const int ntiles = (p.Sk + KT - 1) / KT;
 
     for (int pass = 0; pass < p.npass; ++pass) {
         const AttnEntry& en = p.e[pass * ATT_MAXB + b];
+        if (en.w_const == 0.f && en.w_slope == 0.f) continue;   // block-uniform skip
         float w = en.w_const;
         if (p.w_dev) w += en.w_slope * (*p.w_dev);
-        const bool skip = (en.w_const == 0.f && en.w_slope == 0.f);  // block-uniform
-        if (skip) continue;
+        const bool pass_masked = en.kmask && (!(en.flags & ATT_HEAD_RULE) || (((b * p.heads + head) & 1) == 0));  // block-uniform
 
         // ---- Q^T fragments (B operand of S^T = K.Q^T): lane = query l15 of fragment f, chunk 4s+g ------------
         u32x4 qf[QF][DSL];
@@ -91,8 +115,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
             }
             wq[f] = (en.wq && qok) ? en.wq[q] : 1.f;
             int md = 0;
-            const bool masked = en.kmask && (!(en.flags & ATT_HEAD_RULE) || (((b * p.heads + head) & 1) == 0));
-            if (masked) {
+            if (pass_masked) {
                 const int sel = (en.qsel && qok) ? (en.qsel[q] != 0) : 1;
                 md = sel ? 1 : 2;
                 if (sel && (en.flags & ATT_UNIFORM_SEL1)) md = 3;
@@ -102,7 +125,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         }
 
         f32x4 o[FD][QF];
-        float mrun[QF], lrun[QF];
+        float mrun[QF], lrun[QF];   // running max (already multiplied by c_exp) and per-lane partial row sum
 #pragma unroll
         for (int f = 0; f < QF; ++f) {
             mrun[f] = NEG;
@@ -111,124 +134,150 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
             for (int i = 0; i < FD; ++i) o[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
-        for (int k0 = 0; k0 < p.Sk; k0 += KT) {
-            __syncthreads();  // previous tile fully consumed
-            // ---- stage K tile [KT][DP] and V^T tile [DP][KT] ------------------------------------------------
-            for (int cid = tid; cid < KT * DCH; cid += 256) {
+        // ---- tile staging: global -> registers (issued one tile ahead) -> LDS (double buffered) ----------------------
+        u32x4 rk[NKC], rv[NVC];
+        const T* kbase = Kg + (long)en.kv_row * p.Sk * p.ldk + head * D;
+        const T* vbase = Vg + ((long)en.kv_row * p.heads * D + head * D) * p.ldvt;
+        auto issue = [&](int k0) {
+#pragma unroll
+            for (int i = 0; i < NKC; ++i) {
+                const int cid = tid + 256 * i;
                 const int key = cid / DCH, c = cid - key * DCH;
-                u32x4 v = u32x4{0, 0, 0, 0};
-                if (k0 + key < p.Sk && c * EPC < D)
-                    v = *reinterpret_cast<const u32x4*>(Kg + ((long)en.kv_row * p.Sk + k0 + key) * p.ldk + head * D + c * EPC);
-                *reinterpret_cast<u32x4*>(Ks + key * KROW + c * 16) = v;
+                rk[i] = u32x4{0, 0, 0, 0};
+                if (k0 + key < p.Sk && c * EPC < D) rk[i] = *reinterpret_cast<const u32x4*>(kbase + (long)(k0 + key) * p.ldk + c * EPC);
             }
-            for (int cid = tid; cid < DP * VCH; cid += 256) {
+#pragma unroll
+            for (int i = 0; i < NVC; ++i) {
+                const int cid = tid + 256 * i;
                 const int d = cid / VCH, c = cid - d * VCH;
-                u32x4 v = u32x4{0, 0, 0, 0};
                 const int kk = k0 + c * EPC;
+                rv[i] = u32x4{0, 0, 0, 0};
                 if (d < D) {
-                    const T* src = Vg + ((long)en.kv_row * p.heads * D + head * D + d) * p.ldvt + kk;
+                    const T* src = vbase + (long)d * p.ldvt + kk;
                     if (kk + EPC <= p.Sk) {
-                        v = *reinterpret_cast<const u32x4*>(src);
+                        rv[i] = *reinterpret_cast<const u32x4*>(src);
                     } else if (kk < p.Sk) {
                         float tmp[EPC];
 #pragma unroll
                         for (int e = 0; e < EPC; ++e) tmp[e] = (kk + e < p.Sk) ? DT<T>::ld(src + e) : 0.f;
-                        v = DT<T>::pack(tmp);
+                        rv[i] = DT<T>::pack(tmp);
                     }
                 }
-                *reinterpret_cast<u32x4*>(Vs + d * VROW + c * 16) = v;
             }
-            __syncthreads();
-
-            // ---- S^T = K . Q^T : st[t][f] holds keys 16t+4g+r (r = reg) for query l15 of fragment f ---------
-            f32x4 st[4][QF];
+        };
+        auto stage = [&](int buf) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int i = 0; i < NKC; ++i) {
+                const int cid = tid + 256 * i;
+                const int key = cid / DCH, c = cid - key * DCH;
+                *reinterpret_cast<u32x4*>(Ks + buf * KBUF + key * KROW + c * 16) = rk[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NVC; ++i) {
+                const int cid = tid + 256 * i;
+                const int d = cid / VCH, c = cid - d * VCH;
+                *reinterpret_cast<u32x4*>(Vs + buf * VBUF + d * VROW + c * 16) = rv[i];
+            }
+        };
+
+        // ---- one key tile: S^T = K.Q^T, online softmax, O^T += V^T.P^T ---------------------------------------------
+        auto tile = [&](int k0, int buf, auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            const char* Kb = Ks + buf * KBUF;
+            const char* Vb = Vs + buf * VBUF;
+            f32x4 st[NT][QF];   // st[t][f][r] = score of key 16t+4g+r for query l15 of fragment f
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int f = 0; f < QF; ++f) st[t][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < DSL; ++s) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const u32x4 ka = *reinterpret_cast<const u32x4*>(Ks + (t * 16 + l15) * KROW + (4 * s + g) * 16);
+                for (int t = 0; t < NT; ++t) {
+                    const u32x4 ka = *reinterpret_cast<const u32x4*>(Kb + (t * 16 + l15) * KROW + (4 * s + g) * 16);
 #pragma unroll
                     for (int f = 0; f < QF; ++f) DT<T>::mma(ka, qf[f][s], st[t][f]);
                 }
             }
-
-            // ---- key masks for this lane's keys ------------------------------------------------------------
-            uint32_t km[4];  // byte r of km[t] = kmask[k0 + 16t + 4g + r]
-            bool kin[4][4];
+            // masked path: bit (4t+r) of `inr` = key in range, of `mk` = kmask byte != 0 (keys 16t+4g+r of this lane)
+            uint32_t inr = 0, mk = 0;
+            if (MASKED) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int kb = k0 + t * 16 + 4 * g;
-                km[t] = 0;
-                if (en.kmask) {
-                    if (kb + 4 <= p.Sk)
-                        km[t] = *reinterpret_cast<const uint32_t*>(en.kmask + kb);
-                    else
+                for (int t = 0; t < NT; ++t) {
+                    const int kb = k0 + t * 16 + 4 * g;
+                    uint32_t w4 = 0;
+                    if (kb + 4 <= p.Sk) {
+                        inr |= 0xfu << (4 * t);
+                        if (pass_masked) w4 = *reinterpret_cast<const uint32_t*>(en.kmask + kb);
+                    } else {
                         for (int r = 0; r < 4; ++r)
-                            if (kb + r < p.Sk) km[t] |= (uint32_t)en.kmask[kb + r] << (8 * r);
-                }
+                            if (kb + r < p.Sk) {
+                                inr |= 1u << (4 * t + r);
+                                if (pass_masked) w4 |= (uint32_t)en.kmask[kb + r] << (8 * r);
+                            }
+                    }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) kin[t][r] = (kb + r) < p.Sk;
+                    for (int r = 0; r < 4; ++r) mk |= (((w4 >> (8 * r)) & 0xff) != 0 ? 1u : 0u) << (4 * t + r);
+                }
             }
-
-            // ---- online softmax per query fragment ---------------------------------------------------------
-            u32x4 pb[4 / KPC][QF];  // packed P^T chunks (B operand of O^T = V^T.P^T)
+            u32x4 pb[NT / KPC][QF];  // packed P^T chunks (B operand of O^T = V^T.P^T)
 #pragma unroll
             for (int f = 0; f < QF; ++f) {
-                const int md = mode[f];
-                bool al[4][4];
                 float tmax = NEG;
+                uint32_t am = 0;   // allowed keys of this query
+                if (MASKED) {
+                    const int md = mode[f];
+                    am = inr & (md == 1 ? mk : (md == 2 ? ~mk : 0xffffffffu));
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                    for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool mk = ((km[t] >> (8 * r)) & 0xff) != 0;
-                        bool a = kin[t][r];
-                        if (md == 1) a = a && mk;
-                        if (md == 2) a = a && !mk;
-                        al[t][r] = a;
-                        float sv = (md == 3) ? 0.f : st[t][f][r];
-                        sv = a ? sv : NEG;
-                        st[t][f][r] = sv;
-                        tmax = fmaxf(tmax, sv);
-                    }
+                        for (int r = 0; r < 4; ++r) {
+                            float sv = (md == 3) ? 0.f : st[t][f][r];
+                            sv = ((am >> (4 * t + r)) & 1u) ? sv : NEG;
+                            st[t][f][r] = sv;
+                            tmax = fmaxf(tmax, sv);
+                        }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        tmax = fmaxf(tmax, fmaxf(fmaxf(st[t][f][0], st[t][f][1]), fmaxf(st[t][f][2], st[t][f][3])));
+                }
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-                const float mnew = fmaxf(mrun[f], tmax);
-                const float alpha = exp2f((mrun[f] - mnew) * c_exp);
+                const float mnew = fmaxf(mrun[f], tmax * c_exp);
+                const float alpha = __builtin_amdgcn_exp2f(mrun[f] - mnew);
+                const bool grew = mnew != mrun[f];
                 mrun[f] = mnew;
                 float psum = 0.f;
-                float pv[4][4];
+                float pv[NT][4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float pe = al[t][r] ? exp2f((st[t][f][r] - mnew) * c_exp) : 0.f;
+                        float pe = __builtin_amdgcn_exp2f(fmaf(st[t][f][r], c_exp, -mnew));   // raw v_exp_f32
+                        if (MASKED) pe = ((am >> (4 * t + r)) & 1u) ? pe : 0.f;
                         pv[t][r] = pe;
                         psum += pe;
                     }
                 lrun[f] = lrun[f] * alpha + psum;
+                if (__any(grew)) {   // lazy rescale: exact, skipped once the running max has settled
 #pragma unroll
-                for (int i = 0; i < FD; ++i) o[i][f] *= alpha;
+                    for (int i = 0; i < FD; ++i) o[i][f] *= alpha;
+                }
 #pragma unroll
-                for (int c = 0; c < 4 / KPC; ++c) {
+                for (int c = 0; c < NT / KPC; ++c) {
                     float tmp[EPC];
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) tmp[e] = pv[c * KPC + e / 4][e & 3];
                     pb[c][f] = DT<T>::pack(tmp);
                 }
             }
-
-            // ---- O^T += V^T . P^T ----------------------------------------------------------------------------
 #pragma unroll
-            for (int c = 0; c < 4 / KPC; ++c) {
+            for (int c = 0; c < NT / KPC; ++c) {
 #pragma unroll
                 for (int i = 0; i < FD; ++i) {
                     u32x4 va;
-                    const char* vrow = Vs + (i * 16 + l15) * VROW;
+                    const char* vrow = Vb + (i * 16 + l15) * VROW;
                     if (KPC == 1) {
                         va = *reinterpret_cast<const u32x4*>(vrow + (16 * c + 4 * g) * SZ);
                     } else {
@@ -240,32 +289,42 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                     for (int f = 0; f < QF; ++f) DT<T>::mma(va, pb[c][f], o[i][f]);
                 }
             }
+        };
+
+        issue(0);
+        stage(0);
+        __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            const int k0 = t * KT, buf = t & 1;
+            if (t + 1 < ntiles) issue(k0 + KT);
+            if (pass_masked || k0 + KT > p.Sk)
+                tile(k0, buf, std::true_type{});
+            else
+                tile(k0, buf, std::false_type{});
+            if (t + 1 < ntiles) stage(buf ^ 1);
+            __syncthreads();
         }
 
-        // ---- finish this pass: tot += w * wq[q] * O / l ------------------------------------------------------
+        // ---- finish this pass: acc = (previous passes) + w * wq[q] * O / l; the last active pass stores to HBM ------------
+        ++nseen;
 #pragma unroll
         for (int f = 0; f < QF; ++f) {
             float l = lrun[f];
             l += __shfl_xor(l, 16);
             l += __shfl_xor(l, 32);
             const float sc = (l > 0.f) ? (w * wq[f] / l) : 0.f;
+            const int q = q0 + f * 16 + l15;
 #pragma unroll
-            for (int i = 0; i < FD; ++i) tot[i][f] += o[i][f] * sc;
-        }
-    }
-
-    // ---- store: lane holds O^T[d = 16i + 4g + r][q = l15] -> 4 consecutive d of one query ---------------------
-    T* __restrict__ Og = reinterpret_cast<T*>(p.out);
-#pragma unroll
-    for (int f = 0; f < QF; ++f) {
-        const int q = q0 + f * 16 + l15;
-        if (q >= p.S) continue;
-#pragma unroll
-        for (int i = 0; i < FD; ++i) {
-            const int d = i * 16 + 4 * g;
-            if (d < D) {
-                float v[4] = {tot[i][f][0], tot[i][f][1], tot[i][f][2], tot[i][f][3]};
-                store4(Og + ((long)b * p.S + q) * p.ldo + head * D + d, v);
+            for (int i = 0; i < FD; ++i) {
+                f32x4 v = o[i][f] * sc;
+                if (nseen > 1) v += totl[(i * QF + f) * 64];
+                if (nseen < nactive) {
+                    totl[(i * QF + f) * 64] = v;
+                } else {
+                    const int d = i * 16 + 4 * g;   // lane holds O^T[d = 16i + 4g + r][q = l15] -> 4 consecutive d of one query
+                    float vv[4] = {v[0], v[1], v[2], v[3]};
+                    if (q < p.S && d < D) store4(Og + ((long)b * p.S + q) * p.ldo + head * D + d, vv);
+                }
             }
         }
     }

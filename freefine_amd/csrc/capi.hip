@@ -189,11 +189,13 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
 }
 
 // ---- attention ---------------------------------------------------------------------------------------------------
-template <typename T, int DP, int QF>
+template <typename T, int DP, int QF, int KT = 64, int OCC = 1>
 static int launch_attn(hipStream_t s, const ffn_attn_desc& d) {
     constexpr int SZ = sizeof(T);
-    constexpr int lds = 64 * (DP * SZ + 16) + DP * (64 * SZ + 16);
-    auto kern = attn_kernel<T, DP, QF>;
+    // double-buffered K and V^T tiles + the per-wave multi-pass accumulator
+    constexpr int lds = 2 * (KT * (DP * SZ + 16) + DP * (KT * SZ + 16)) + 4 * (DP / 16) * QF * 64 * 16;
+    static_assert(lds <= 160 * 1024, "attention tile does not fit the 160 KiB LDS");
+    auto kern = attn_kernel<T, DP, QF, KT, OCC>;
     static bool lds_set = false;
     if (!lds_set) {
         int rc = set_lds(kern, lds);
@@ -222,9 +224,9 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
         if (D <= 48) return launch_attn<float, 48, 2>(s, *d);
         if (D <= 64) return launch_attn<float, 64, 2>(s, *d);
         if (D <= 80) return launch_attn<float, 80, 2>(s, *d);
-        if (D <= 160) return launch_attn<float, 160, 1>(s, *d);
+        if (D <= 160) return launch_attn<float, 160, 1, 32>(s, *d);
     } else {
-        if (D <= 64) return launch_attn<bf16, 64, 2>(s, *d);
+        if (D <= 64) return launch_attn<bf16, 64, 2, 64, 2>(s, *d);
         if (D <= 96) return launch_attn<bf16, 96, 2>(s, *d);
         if (D <= 160) return launch_attn<bf16, 160, 1>(s, *d);
     }

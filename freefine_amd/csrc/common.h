@@ -30,6 +30,13 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     __bf16 h = (__bf16)f;
     return __builtin_bit_cast(uint16_t, h);
 }
+// two floats -> one dword of two bf16 (lo in bits 0..15): ONE v_cvt_pk_bf16_f32
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const bf16x2_t h = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, h);
+}
 
 template <typename T>
 struct DT;
@@ -77,8 +84,7 @@ struct DT<bf16> {
     }
     __device__ static __forceinline__ u32x4 pack(const float* f) {
         u32x4 c;
-        for (int i = 0; i < 4; ++i)
-            c[i] = (uint32_t)f32_to_bf16(f[2 * i]) | ((uint32_t)f32_to_bf16(f[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) c[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
         return c;
     }
 };
@@ -89,8 +95,8 @@ __device__ __forceinline__ void store4(float* p, const float* v) {
 }
 __device__ __forceinline__ void store4(bf16* p, const float* v) {
     u32x2 w;
-    w[0] = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    w[1] = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    w[0] = pack_bf16x2(v[0], v[1]);
+    w[1] = pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<u32x2*>(p) = w;
 }
 __device__ __forceinline__ void load4(const float* p, float* v) {
