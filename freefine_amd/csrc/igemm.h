@@ -24,6 +24,135 @@ enum { AMODE_DENSE = 0, AMODE_CONV3 = 1 };
 enum { IG_OUT_SILU = FFN_IG_OUT_SILU, IG_OUT_F32 = FFN_IG_OUT_F32, IG_GEGLU = FFN_IG_GEGLU, IG_OUT_TRANSPOSED = FFN_IG_OUT_TRANSPOSED };
 typedef ffn_igemm_desc IgemmParams;
 
+// epilogue shared by the igemm kernels: acc[i][j] is the 16x16 fragment (i, j) of this wave's (BM/2) x (BN/2) sub-tile
+template <typename T, int BM, int BN, bool SWAP>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[BM / 32][BN / 32], int m0, int n0, int wm, int wn,
+                                               int l15, int g) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    // ---- epilogue --------------------------------------------------------------------------------
+    T* __restrict__ outT = reinterpret_cast<T*>(p.out);
+    float* __restrict__ outF = reinterpret_cast<float*>(p.out);
+    const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+    const bool out_f32 = p.flags & IG_OUT_F32;
+    const bool out_silu = p.flags & IG_OUT_SILU;
+
+    if (SWAP && gridDim.y > 1) {
+        // split-K partial: raw fp32 accumulators to slab blockIdx.y of the workspace
+        float* __restrict__ slab = reinterpret_cast<float*>(p.ws) + (long)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * WM + i * 16 + l15;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + 4 * g;
+                if (m < p.M && n < p.N) {
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    store4(slab + (long)m * p.N + n, v);
+                }
+            }
+        }
+        return;
+    }
+    if (SWAP) {
+        // lane holds C[m = ..+l15][n = ..+4g+r], r = 0..3: four consecutive columns of one row
+        if (p.flags & IG_GEGLU) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * WM + i * 16 + l15;
+#pragma unroll
+                for (int j = 0; j < FN; j += 2) {
+                    const int nh = n0 + wn * WN + j * 16 + 4 * g;  // packed column of the hidden half
+                    if (m < p.M && nh < p.N) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float h = acc[i][j][r] * p.alpha, gt = acc[i][j + 1][r] * p.alpha;
+                            if (p.bias) {
+                                h += p.bias[nh + r];
+                                gt += p.bias[nh + 16 + r];
+                            }
+                            v[r] = h * gelu_erf(gt);
+                        }
+                        const int no = (n0 + wn * WN) / 2 + (j / 2) * 16 + 4 * g;
+                        store4(outT + (long)m * p.ldo + no, v);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * WM + i * 16 + l15;
+                const int bb = m / p.rows_per_batch;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int n = n0 + wn * WN + j * 16 + 4 * g;
+                    if (m < p.M && n < p.N) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float x = acc[i][j][r] * p.alpha;
+                            if (p.bias) x += p.bias[n + r];
+                            if (p.rowbias) x += p.rowbias[(long)bb * p.ldrb + n + r];
+                            if (out_silu) x = silu_exact(x);
+                            v[r] = x;
+                        }
+                        if (res) {
+                            float rr[4];
+                            load4(res + (long)m * p.ldr + n, rr);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                        }
+                        if (out_f32)
+                            store4(outF + (long)m * p.ldo + n, v);
+                        else
+                            store4(outT + (long)m * p.ldo + n, v);
+                    }
+                }
+            }
+        }
+    } else {
+        // lane holds C[m = ..+4g+r][n = ..+l15]: four consecutive rows of one column -> transposed store
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int mb = m0 + wm * WM + i * 16 + 4 * g;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + l15;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[i][j][r] * p.alpha;
+                    if (p.bias) x += p.bias[n];
+                    v[r] = x;
+                }
+                if (p.flags & IG_OUT_TRANSPOSED) {
+                    const int bb = mb / p.rows_per_batch, s = mb - bb * p.rows_per_batch;
+                    if ((p.rows_per_batch & 3) == 0 && mb + 3 < p.M) {
+                        store4(outT + ((long)bb * p.N + n) * p.ldo + s, v);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = mb + r;
+                            if (m < p.M) {
+                                const int b2 = m / p.rows_per_batch, s2 = m - b2 * p.rows_per_batch;
+                                DT<T>::st(outT + ((long)b2 * p.N + n) * p.ldo + s2, v[r]);
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = mb + r;
+                        if (m < p.M) DT<T>::st(outT + (long)m * p.ldo + n, v[r]);
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int BM, int BN, int AMODE, bool SWAP>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int EPC = DT<T>::EPC;
@@ -168,127 +297,165 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue --------------------------------------------------------------------------------
-    T* __restrict__ outT = reinterpret_cast<T*>(p.out);
-    float* __restrict__ outF = reinterpret_cast<float*>(p.out);
-    const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
-    const bool out_f32 = p.flags & IG_OUT_F32;
-    const bool out_silu = p.flags & IG_OUT_SILU;
+    igemm_epilogue<T, BM, BN, SWAP>(p, acc, m0, n0, wm, wn, l15, g);
+}
 
-    if (SWAP && gridDim.y > 1) {
-        // split-K partial: raw fp32 accumulators to slab blockIdx.y of the workspace
-        float* __restrict__ slab = reinterpret_cast<float*>(p.ws) + (long)blockIdx.y * p.M * p.N;
+// ---------------------------------------------------------------------------------------------------------------------
+// igemm_glds_kernel: same tile / fragment / epilogue scheme as igemm_kernel, but both operand tiles are staged with
+// direct-to-LDS loads (global_load_lds_dwordx4): no VGPR round trip and no ds_write (on gfx950 a ds_write_b128 stream
+// delivers only ~80 B/clk/CU, which made the register-staged loader's LDS writes as expensive as the MFMAs).
+// The LDS image must be lane-linear per wave instruction (8 rows x 128 B = 1 KiB), so the XOR swizzle is applied to
+// the SOURCE address: the lane that owns LDS slot c of row r fetches global chunk c ^ (r & 7).  Out-of-range chunks
+// (conv zero padding, M/N/K tails) are fetched from a 16-byte zero page.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) const uint32_t g_zero_chunk[4] = {0, 0, 0, 0};
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <typename T, int BM, int BN, int AMODE, bool SWAP, int NS = 2>   // NS = LDS ring depth (stages in flight = NS-1)
+__global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p) {
+    constexpr int EPC = DT<T>::EPC;
+    constexpr int BKE = 8 * EPC;  // K elements per stage (128 bytes)
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int NA = BM / 32, NB = BN / 32;  // wave-instructions (8 rows each) per wave per stage
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                    // [NS][BM][128]
+    char* Bs = smem + NS * BM * 128;    // [NS][BN][128]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+
+    const int ntn = (p.N + BN - 1) / BN;
+    const int ntm = (p.M + BM - 1) / BM;
+    const int L = xcd_remap(blockIdx.x, ntm * ntn);
+    const int m0 = (L / ntn) * BM, n0 = (L % ntn) * BN;
+
+    const int lrow = lane >> 3;             // row inside this wave-instruction's 8-row group
+    const int csrc = (lane & 7) ^ lrow;     // global chunk this lane fetches (source-side swizzle)
+    const char* zero = reinterpret_cast<const char*>(g_zero_chunk);
+
+    const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A);
+    const T* __restrict__ Wg = reinterpret_cast<const T*>(p.W);
+    long a_base[NA];
+    int a_y[NA], a_x[NA];
+    bool a_ok[NA];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int m = m0 + wm * WM + i * 16 + l15;
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int n = n0 + wn * WN + j * 16 + 4 * g;
-                if (m < p.M && n < p.N) {
-                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                    store4(slab + (long)m * p.N + n, v);
-                }
-            }
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + 8 * wave + 32 * i + lrow;
+        a_ok[i] = m < p.M;
+        if (AMODE == AMODE_DENSE) {
+            a_base[i] = (long)m * p.lda;
+            a_y[i] = a_x[i] = 0;
+        } else {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, rem = m - b * hw;
+            const int yo = rem / p.Wout, xo = rem - yo * p.Wout;
+            a_base[i] = (long)b * p.Hin * p.Win;
+            a_y[i] = yo * p.stride - p.pad;
+            a_x[i] = xo * p.stride - p.pad;
         }
-        return;
     }
-    if (SWAP) {
-        // lane holds C[m = ..+l15][n = ..+4g+r], r = 0..3: four consecutive columns of one row
-        if (p.flags & IG_GEGLU) {
+    long b_base[NB];
+    bool b_ok[NB];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int m = m0 + wm * WM + i * 16 + l15;
+    for (int i = 0; i < NB; ++i) {
+        const int n = n0 + 8 * wave + 32 * i + lrow;
+        b_ok[i] = n < p.N;
+        b_base[i] = (long)n * p.Kpad;
+    }
+    const int He = p.Hin << p.upsample, We = p.Win << p.upsample;
+
+    auto issue = [&](int kt, int buf) {
+        const int kk = kt * BKE + csrc * EPC;
+        const bool kin = kk < p.K;
+        if (AMODE == AMODE_DENSE) {
 #pragma unroll
-                for (int j = 0; j < FN; j += 2) {
-                    const int nh = n0 + wn * WN + j * 16 + 4 * g;  // packed column of the hidden half
-                    if (m < p.M && nh < p.N) {
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float h = acc[i][j][r] * p.alpha, gt = acc[i][j + 1][r] * p.alpha;
-                            if (p.bias) {
-                                h += p.bias[nh + r];
-                                gt += p.bias[nh + 16 + r];
-                            }
-                            v[r] = h * gelu_erf(gt);
-                        }
-                        const int no = (n0 + wn * WN) / 2 + (j / 2) * 16 + 4 * g;
-                        store4(outT + (long)m * p.ldo + no, v);
-                    }
-                }
+            for (int i = 0; i < NA; ++i) {
+                const char* src = (a_ok[i] && kin) ? reinterpret_cast<const char*>(Ag + a_base[i] + kk) : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * BM * 128 + (8 * wave + 32 * i) * 128), 16, 0, 0);
             }
         } else {
+            const int tap = kk / p.Cin, ci = kk - tap * p.Cin;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                int yy = a_y[i] + ky, xx = a_x[i] + kx;
+                const bool inb = a_ok[i] && kin && yy >= 0 && yy < He && xx >= 0 && xx < We;
+                yy >>= p.upsample;
+                xx >>= p.upsample;
+                const char* src = inb ? reinterpret_cast<const char*>(Ag + (a_base[i] + (long)yy * p.Win + xx) * p.Cin + ci) : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * BM * 128 + (8 * wave + 32 * i) * 128), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const char* src = (b_ok[i] && kin) ? reinterpret_cast<const char*>(Wg + b_base[i] + kk) : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + buf * BN * 128 + (8 * wave + 32 * i) * 128), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+        const char* Ab = As + buf * BM * 128;
+        const char* Bb = Bs + buf * BN * 128;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 fa[FM], fb[FN];
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int m = m0 + wm * WM + i * 16 + l15;
-                const int bb = m / p.rows_per_batch;
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const int n = n0 + wn * WN + j * 16 + 4 * g;
-                    if (m < p.M && n < p.N) {
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float x = acc[i][j][r] * p.alpha;
-                            if (p.bias) x += p.bias[n + r];
-                            if (p.rowbias) x += p.rowbias[(long)bb * p.ldrb + n + r];
-                            if (out_silu) x = silu_exact(x);
-                            v[r] = x;
-                        }
-                        if (res) {
-                            float rr[4];
-                            load4(res + (long)m * p.ldr + n, rr);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += rr[r];
-                        }
-                        if (out_f32)
-                            store4(outF + (long)m * p.ldo + n, v);
-                        else
-                            store4(outT + (long)m * p.ldo + n, v);
-                    }
-                }
+                const int row = wm * WM + i * 16 + l15;
+                fa[i] = *reinterpret_cast<const u32x4*>(Ab + row * 128 + (((4 * s + g) ^ (row & 7)) << 4));
             }
-        }
-    } else {
-        // lane holds C[m = ..+4g+r][n = ..+l15]: four consecutive rows of one column -> transposed store
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int mb = m0 + wm * WM + i * 16 + 4 * g;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int n = n0 + wn * WN + j * 16 + l15;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = acc[i][j][r] * p.alpha;
-                    if (p.bias) x += p.bias[n];
-                    v[r] = x;
-                }
-                if (p.flags & IG_OUT_TRANSPOSED) {
-                    const int bb = mb / p.rows_per_batch, s = mb - bb * p.rows_per_batch;
-                    if ((p.rows_per_batch & 3) == 0 && mb + 3 < p.M) {
-                        store4(outT + ((long)bb * p.N + n) * p.ldo + s, v);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int m = mb + r;
-                            if (m < p.M) {
-                                const int b2 = m / p.rows_per_batch, s2 = m - b2 * p.rows_per_batch;
-                                DT<T>::st(outT + ((long)b2 * p.N + n) * p.ldo + s2, v[r]);
-                            }
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = mb + r;
-                        if (m < p.M) DT<T>::st(outT + (long)m * p.ldo + n, v[r]);
-                    }
-                }
+                const int row = wn * WN + j * 16 + l15;
+                fb[j] = *reinterpret_cast<const u32x4*>(Bb + row * 128 + (((4 * s + g) ^ (row & 7)) << 4));
             }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    if (SWAP)
+                        DT<T>::mma(fb[j], fa[i], acc[i][j]);
+                    else
+                        DT<T>::mma(fa[i], fb[j], acc[i][j]);
+                }
         }
+    };
+
+    const int nk_all = (p.K + BKE - 1) / BKE;
+    const int spp = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kt0 = blockIdx.y * spp;
+    const int nk = min(nk_all, kt0 + spp);
+
+    // ring of NS LDS stages, NS-1 of them in flight; every issue() is exactly NLD wave-instructions, so "stage kt has landed"
+    // is a COUNTED wait (vmcnt = NLD x stages issued after it), the DMA of later stages stays in flight across the barrier
+    constexpr int NLD = NA + NB;
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (kt0 + s < nk) issue(kt0 + s, s);
+    int buf = 0;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int ahead = min(NS - 2, nk - 1 - kt);     // stages issued after stage kt
+        if (NS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+        else if (NS >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // stage kt visible to all waves; all waves are done with stage kt-1 -> its buffer is free
+        if (kt + NS - 1 < nk) issue(kt + NS - 1, (buf + NS - 1) % NS);
+        compute(buf);
+        buf = (buf + 1 == NS) ? 0 : buf + 1;
     }
+    igemm_epilogue<T, BM, BN, SWAP>(p, acc, m0, n0, wm, wn, l15, g);
 }
 
 // split-K finish: out[m, n..n+3] = epilogue(sum_s slab[s][m][n..n+3])  (same epilogue as the SWAP path of igemm_kernel)

@@ -31,8 +31,26 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
         float s[EPC], ss[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) s[e] = ss[e] = 0.f;
-        for (int px = p0 + pp; px < p1; px += ppi) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(x + ((long)b * HW + px) * C + cc * EPC);
+        // four pixels in flight per thread: a single dependent load per iteration made this kernel latency bound
+        const T* src = x + ((long)b * HW) * C + cc * EPC;
+        int px = p0 + pp;
+        for (; px + 3 * ppi < p1; px += 4 * ppi) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u32x4*>(src + (long)(px + u * ppi) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[EPC];
+                DT<T>::unpack(v[u], f);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    s[e] += f[e];
+                    ss[e] += f[e] * f[e];
+                }
+            }
+        }
+        for (; px < p1; px += ppi) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(src + (long)px * C);
             float f[EPC];
             DT<T>::unpack(v, f);
 #pragma unroll
@@ -107,6 +125,66 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
             f[e] = t;
         }
         *reinterpret_cast<u32x4*>(y + i * EPC) = DT<T>::pack(f);
+    }
+}
+
+// ---- fused GroupNorm for slices that one workgroup can own: grid (G, B), 1024 threads ----------------------------------
+// pass 1: sum / sumsq over the (batch, group) slice [HW][cg] (element pairs, 4 or 8 bytes per load; the slice is L2 resident),
+// block reduction (fp32 per thread, fp64 across threads), pass 2: y = act((x - mean) * rstd * gamma + beta).
+template <typename T, bool SILU>
+__global__ __launch_bounds__(1024) void gn_fused_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int HW, int C, int G, float eps) {
+    __shared__ double red[2][16];
+    __shared__ float stat[2];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = C / G, hp = cg / 2;                      // channel pairs per pixel in this group
+    const long base = (long)b * HW * C + (long)g * cg;
+    const int npair = HW * hp;
+    float s = 0.f, ss = 0.f;
+    for (int i = tid; i < npair; i += 1024) {
+        const int px = i / hp, c2 = i - px * hp;
+        const T* src = x + base + (long)px * C + 2 * c2;
+        const float a = DT<T>::ld(src), c = DT<T>::ld(src + 1);
+        s += a + c;
+        ss += a * a + c * c;
+    }
+    double ds = s, dss = ss;
+    for (int off = 32; off > 0; off >>= 1) {
+        ds += __shfl_xor(ds, off);
+        dss += __shfl_xor(dss, off);
+    }
+    if (lane == 0) {
+        red[0][wave] = ds;
+        red[1][wave] = dss;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0, tt = 0;
+        for (int w = 0; w < 16; ++w) {
+            t += red[0][w];
+            tt += red[1][w];
+        }
+        const double n = (double)HW * cg, mean = t / n;
+        double var = tt / n - mean * mean;
+        if (var < 0) var = 0;
+        stat[0] = (float)mean;
+        stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const float mean = stat[0], rstd = stat[1];
+    for (int i = tid; i < npair; i += 1024) {
+        const int px = i / hp, c2 = i - px * hp;
+        const int c = g * cg + 2 * c2;
+        const long off = base + (long)px * C + 2 * c2;
+        const float sc0 = rstd * gamma[c], sc1 = rstd * gamma[c + 1];
+        float a = DT<T>::ld(x + off) * sc0 + (beta[c] - mean * sc0);
+        float d = DT<T>::ld(x + off + 1) * sc1 + (beta[c + 1] - mean * sc1);
+        if (SILU) {
+            a = silu_exact(a);
+            d = silu_exact(d);
+        }
+        DT<T>::st(y + off, a);
+        DT<T>::st(y + off + 1, d);
     }
 }
 

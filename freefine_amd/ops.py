@@ -272,18 +272,17 @@ def gn_workspace(B, HW, C, device):
 
 
 def groupnorm(x, gamma, beta, G, eps, silu=False, out=None, ws=None):
-    """x: [B, HW, C]."""
+    """x: [B, HW, C].  One fused launch for slices <= 131072 elements per (batch, group), else stats + apply."""
     lib = L.load()
     B, HW, Cc = x.shape
-    if ws is None:
-        ws = gn_workspace(B, HW, Cc, x.device)
-    partial, scale, shift = ws
-    L.check(lib.ffn_gn_stats(_stream(), _dt(x), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B, HW, Cc, G, eps,
-                             partial.data_ptr(), scale.data_ptr(), shift.data_ptr()), "ffn_gn_stats")
     if out is None:
         out = torch.empty_like(x)
-    L.check(lib.ffn_gn_apply(_stream(), _dt(x), x.data_ptr(), out.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, HW, Cc,
-                             1 if silu else 0), "ffn_gn_apply")
+    if HW <= 1024 and HW * (Cc // G) <= 131072:
+        partial = scale = shift = None
+    else:
+        partial, scale, shift = ws if ws is not None else gn_workspace(B, HW, Cc, x.device)
+    L.check(lib.ffn_groupnorm(_stream(), _dt(x), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B, HW, Cc, G, eps,
+                              1 if silu else 0, _p(partial), _p(scale), _p(shift)), "ffn_groupnorm")
     return out
 
 

@@ -107,6 +107,10 @@ int ffn_gn_stats(void* stream, int dtype, const void* x, const float* gamma, con
                  float eps, float* partial_ws, float* scale, float* shift);
 int ffn_gn_apply(void* stream, int dtype, const void* x, void* y, const float* scale, const float* shift, int B, int HW,
                  int C, int silu);
+/* GroupNorm (+ optional SiLU) in one call: a single fused launch when a (batch, group) slice has <= 131072 elements (every UNet
+ * GroupNorm at 64x64 latents), else ffn_gn_stats + ffn_gn_apply (workspace pointers may be NULL in the fused case). */
+int ffn_groupnorm(void* stream, int dtype, const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int G,
+                  float eps, int silu, float* partial_ws, float* scale, float* shift);
 int ffn_layernorm(void* stream, int dtype, const void* x, void* y, const float* gamma, const float* beta, int M, int C,
                   float eps);
 int ffn_softmax_rows(void* stream, int dtype, const void* x, void* y, long M, int N, float scale);

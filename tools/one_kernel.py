@@ -1,0 +1,38 @@
+"""Run ONE kernel shape repeatedly (for rocprofv3 --pmc passes).  python tools/one_kernel.py conv 64 320 320 | gemm M K N | attn S C heads passes"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from freefine_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+dt = torch.bfloat16
+g = torch.Generator().manual_seed(0)
+rnd = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(dt).to(dev)
+kind = sys.argv[1]
+B = 4
+if kind == "conv":
+    hw, cin, cout = map(int, sys.argv[2:5])
+    x = rnd(B, hw * hw, cin)
+    w = ops.pack_conv3x3(rnd(cout, cin, 3, 3, scale=(9 * cin) ** -0.5), dt)
+    b = torch.zeros(cout, device=dev)
+    fn = lambda: ops.conv3x3(x, w, b, B, hw, hw, cin)
+elif kind == "gemm":
+    M, K, N = map(int, sys.argv[2:5])
+    x = rnd(M, K)
+    w = ops.pack_linear(rnd(N, K, scale=K ** -0.5), dt)
+    fn = lambda: ops.linear(x, w, None)
+else:
+    S, C, heads, passes = map(int, sys.argv[2:6])
+    q, k, vt = rnd(B, S, C), rnd(B, S, C), rnd(B, C, S)
+    km = (torch.rand(S, generator=g) > 0.7).to(torch.uint8).to(dev)
+    qs = (torch.rand(S, generator=g) > 0.5).to(torch.uint8).to(dev)
+    cg = torch.tensor([0.5], device=dev)
+    P = None if passes == 1 else [[ops.AttnEntrySpec(b, [1, 1, 3, 3][b], 0.0, 1.0, kmask=km, qsel=qs, flags=1) for b in range(B)],
+                                  [ops.AttnEntrySpec(b, b, 1.0, -1.0) for b in range(B)]]
+    fn = lambda: ops.attention(q, k, vt, heads, (C // heads) ** -0.5, P, w_dev=cg)
+for _ in range(10):
+    fn()
+torch.cuda.synchronize()
