@@ -68,6 +68,7 @@ def build_model(args, device, rank, world):
     register_attention_control(model, controller)
     model.modify_unet_forward()
     model.unet.use_graph = not args.no_graph
+    model.dedup_rows = not args.no_dedup
     return model
 
 
@@ -148,6 +149,7 @@ def main():
     ap.add_argument("--num-step", dest="num_step", type=int, default=50)
     ap.add_argument("--start-step", dest="start_step", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-dedup", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-skip-vae", action="store_true")
@@ -195,6 +197,7 @@ def main():
                                    f"(start_step={args.start_step}: {n} inversion forwards B=2 + {n} guided forwards B=4, TCA blocks 10-15, "
                                    "masked CFG 7.5, eta=1) + VAE bracket; seeded random weights",
                        "images_per_gpu_per_step": 1, "unet_batch": 4, "hip_graph": not args.no_graph,
+                       "exact_row_dedup": model.dedup_rows and "on: the duplicated reference row of the CFG batch is evaluated once (3 physical rows), outputs unchanged",
                        "algorithmic_tflop_per_image": round(f_img / 1e12, 1),
                        "whole_path_tflops_per_gpu": round(f_img * value / world / 1e12, 1),
                        "whole_path_frac_of_mfma_peak": round(f_img * value / world / 1e12 / PEAK_TFLOPS[args.dtype], 4)},

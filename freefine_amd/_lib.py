@@ -33,7 +33,7 @@ class AttnEntry(C.Structure):
         ("q_row", C.c_int), ("kv_row", C.c_int),
         ("w_const", C.c_float), ("w_slope", C.c_float),
         ("wq", C.c_void_p), ("kmask", C.c_void_p), ("qsel", C.c_void_p),
-        ("flags", C.c_int), ("pad_", C.c_int),
+        ("flags", C.c_int), ("hr_row", C.c_int),
     ]
 
 

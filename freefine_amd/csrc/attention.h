@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
         if (en.w_const == 0.f && en.w_slope == 0.f) continue;   // block-uniform skip
         float w = en.w_const;
         if (p.w_dev) w += en.w_slope * (*p.w_dev);
-        const bool pass_masked = en.kmask && (!(en.flags & ATT_HEAD_RULE) || (((b * p.heads + head) & 1) == 0));  // block-uniform
+        const int hb = en.hr_row > 0 ? en.hr_row - 1 : b;   // batch row the reference's j = b*heads + head refers to
+        const bool pass_masked = en.kmask && (!(en.flags & ATT_HEAD_RULE) || (((hb * p.heads + head) & 1) == 0));  // block-uniform
 
         // ---- Q^T fragments (B operand of S^T = K.Q^T): lane = query l15 of fragment f, chunk 4s+g ------------
         u32x4 qf[QF][DSL];

@@ -214,11 +214,16 @@ def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, ou
 # ---------------------------------------------------------------------------------------------------------------
 class AttnEntrySpec:
     """One (pass, output-row) term of ffn_attn (see include/freefine_hip.h)."""
-    __slots__ = ("q_row", "kv_row", "w_const", "w_slope", "wq", "kmask", "qsel", "flags")
+    __slots__ = ("q_row", "kv_row", "w_const", "w_slope", "wq", "kmask", "qsel", "flags", "hr_row")
 
-    def __init__(self, q_row, kv_row, w_const=1.0, w_slope=0.0, wq=None, kmask=None, qsel=None, flags=0):
+    def __init__(self, q_row, kv_row, w_const=1.0, w_slope=0.0, wq=None, kmask=None, qsel=None, flags=0, hr_row=None):
         self.q_row, self.kv_row, self.w_const, self.w_slope = q_row, kv_row, w_const, w_slope
-        self.wq, self.kmask, self.qsel, self.flags = wq, kmask, qsel, flags
+        self.wq, self.kmask, self.qsel, self.flags, self.hr_row = wq, kmask, qsel, flags, hr_row
+
+    def remap(self, row_map, logical_row):
+        """the same term for a row-deduplicated batch: Q / KV rows through logical->physical, head rule pinned to the logical row"""
+        return AttnEntrySpec(row_map[self.q_row], row_map[self.kv_row], self.w_const, self.w_slope, self.wq, self.kmask, self.qsel,
+                             self.flags, logical_row if self.hr_row is None else self.hr_row)
 
 
 def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=None, Bo=None, C=None):
@@ -248,6 +253,7 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
                 continue
             e.q_row, e.kv_row, e.w_const, e.w_slope = sp.q_row, sp.kv_row, sp.w_const, sp.w_slope
             e.wq, e.kmask, e.qsel, e.flags = _p(sp.wq), _p(sp.kmask), _p(sp.qsel), sp.flags
+            e.hr_row = 0 if sp.hr_row is None else sp.hr_row + 1
     if _PROF is None:
         L.check(lib.ffn_attn(_stream(), _dt(q), CT.byref(d)), "ffn_attn")
     else:

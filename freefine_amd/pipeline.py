@@ -52,6 +52,7 @@ class FreeFinePipeline:
         self.controller = None
         self.method_type = None
         self.noise_device = "cpu"
+        self.dedup_rows = True      # exact: identical (latent, text) rows of the CFG batch are evaluated once
 
     # ------------------------------------------------------------------------------------------------------------
     # construction (freefine_batch_infer_2d.py:148-157)
@@ -241,6 +242,23 @@ class FreeFinePipeline:
             return latents, latents_list
         return latents
 
+    def _cfg_row_map(self, text, n):
+        """CFG batch rows are (latent i mod n, text row i).  Rows whose text embeddings coincide are the same UNet input, bit
+        for bit (edit / bg-gen: the reference stream with prompt "" appears twice; with an empty edit prompt so does the edit
+        stream) -> evaluate each distinct row once.  Returns (row_map or None, physical latent rows, physical text rows)."""
+        if not self.dedup_rows:
+            return None, None, None
+        row_map, phys = [], []
+        for i in range(2 * n):
+            hit = next((j for j, (li, ti) in enumerate(phys) if li == i % n and torch.equal(text[ti], text[i])), None)
+            if hit is None:
+                phys.append((i % n, i))
+                hit = len(phys) - 1
+            row_map.append(hit)
+        if len(phys) == 2 * n:
+            return None, None, None
+        return row_map, [li for li, _ in phys], [ti for _, ti in phys]
+
     def _configure_method(self, method_type, share_attn=True):
         self.method_type = method_type
         c = self.controller
@@ -281,6 +299,8 @@ class FreeFinePipeline:
         latents_list = [latents]
         start_step = num_inference_steps - num_actual_inference_steps
         cfg_f = self._mask_f(completion_mask_cfg) if local_edit_text else None
+        row_map, lat_rows, txt_rows = self._cfg_row_map(text, 2)
+        text_phys = text[txt_rows].contiguous() if row_map is not None else text
         for i, t in enumerate(self.scheduler.timesteps):
             if i < start_step:
                 continue
@@ -293,7 +313,10 @@ class FreeFinePipeline:
                 self.controller.context_guidance = self.linear_param(i, start_step, end_step, num_inference_steps, end_scale=end_scale)
             elif method_type == "mmsa_es" and i >= end_step:
                 self.controller.use_tca = False
-            noise_pred = self.unet(torch.cat([latents] * 2), t, encoder_hidden_states=text)
+            if row_map is None:
+                noise_pred = self.unet(torch.cat([latents] * 2), t, encoder_hidden_states=text)
+            else:
+                noise_pred = self.unet(latents[lat_rows], t, encoder_hidden_states=text_phys, row_map=row_map)
             eu, ec = noise_pred.chunk(2, dim=0)
             noise_pred = ops.cfg_masked(eu.contiguous(), ec.contiguous(), cfg_f, guidance_scale)
             mask = local_var_reg if local_perturbation else torch.ones_like(local_var_reg)
@@ -325,6 +348,8 @@ class FreeFinePipeline:
         latents_list = [latents]
         start_step = num_inference_steps - num_actual_inference_steps
         cfg_f = self._mask_f(local_cfg_reg) if local_text_edit else None
+        row_map, lat_rows, txt_rows = self._cfg_row_map(text, 2)
+        text_phys = text[txt_rows].contiguous() if row_map is not None else text
         for i, t in enumerate(self.scheduler.timesteps):
             if i < start_step:
                 continue
@@ -336,7 +361,10 @@ class FreeFinePipeline:
                 self.controller.context_guidance = self.linear_param(i, start_step, end_step, num_inference_steps, end_scale=end_scale)
             elif method_type == "mmsa_es" and i >= end_step:
                 self.controller.use_tca = False
-            noise_pred = self.unet(torch.cat([latents] * 2), t, encoder_hidden_states=text)
+            if row_map is None:
+                noise_pred = self.unet(torch.cat([latents] * 2), t, encoder_hidden_states=text)
+            else:
+                noise_pred = self.unet(latents[lat_rows], t, encoder_hidden_states=text_phys, row_map=row_map)
             eu, ec = noise_pred.chunk(2, dim=0)
             noise_pred = ops.cfg_masked(eu.contiguous(), ec.contiguous(), cfg_f, guidance_scale)
             mask = local_var_reg if local_perturbation else torch.ones_like(local_var_reg)

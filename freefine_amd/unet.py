@@ -33,6 +33,7 @@ class HipUNet:
         self._graphs = {}
         self._text_bufs = {}
         self.use_graph = False
+        self._row_map = None
         self._pack(state)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -138,8 +139,8 @@ class HipUNet:
     def to(self, *a, **k):
         return self
 
-    def __call__(self, sample, timestep, encoder_hidden_states=None, **kw):
-        return self.forward(sample, timestep, encoder_hidden_states)
+    def __call__(self, sample, timestep, encoder_hidden_states=None, row_map=None, **kw):
+        return self.forward(sample, timestep, encoder_hidden_states, row_map)
 
     # ------------------------------------------------------------------------------------------------------------
     # text-side precompute: cross-attention K and V^T for all 16 blocks (constant across the sampling loop)
@@ -167,22 +168,26 @@ class HipUNet:
     # ------------------------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------------------------
-    def forward(self, sample, timestep, enc):
-        """sample [B,Cin,h,w] fp32 (cuda), timestep int/0-d tensor, enc [Bt,77,D] -> eps [B,Cout,h,w] fp32."""
+    def forward(self, sample, timestep, enc, row_map=None):
+        """sample [B,Cin,h,w] fp32 (cuda), timestep int/0-d tensor, enc [Bt,77,D] -> eps [B,Cout,h,w] fp32.
+        row_map (optional): the caller's LOGICAL batch has len(row_map) rows of which only the distinct ones were passed in
+        (`sample`/`enc` hold the physical rows, row_map[logical] = physical): the attention controller still plans for the
+        logical batch, its pass tables are translated, and the result is expanded back to the logical batch."""
         sample = sample.to(self.device, torch.float32).contiguous()
         B = sample.shape[0]
+        self._row_map = tuple(row_map) if row_map is not None else None
         self.t_dev.fill_(float(timestep))
         c = self.controller
         if c is not None and c.context_guidance is not None:
             self.cg_dev.fill_(float(c.context_guidance))
         text_kv = self.prepare_text(enc)
         if not self.use_graph:
-            return self._run(sample, text_kv)
+            return self._expand(self._run(sample, text_kv))
         # graph mode: plan every attention call first (this also refreshes the controller's static mask vectors and
         # advances its counters exactly as an eager forward would); the plans' fingerprint is part of the graph key
         state = (c.cur_att_layer, c.cur_step) if c is not None else None
         fp = self._plan_all(B, sample.shape[2], sample.shape[3])
-        sig = (B, tuple(sample.shape), tuple(enc.shape), fp)
+        sig = (B, tuple(sample.shape), tuple(enc.shape), fp, self._row_map)
         g = self._graphs.get(sig)
         if g is None:
             if c is not None:
@@ -190,7 +195,28 @@ class HipUNet:
             g = self._capture(sample, text_kv, sig)
         g["x"].copy_(sample)
         g["graph"].replay()
-        return g["out"].clone()
+        return self._expand(g["out"].clone())
+
+    def _expand(self, eps):
+        if self._row_map is None:
+            return eps
+        return eps[list(self._row_map)]
+
+    def _plan(self, is_cross, place, B, S, heads):
+        """controller plan for the logical batch, translated to the physical (deduplicated) rows"""
+        c = self.controller
+        rm = self._row_map
+        plan = c.plan(self.hook, is_cross, place, len(rm) if rm is not None else B, S, heads, self.device)
+        if rm is None or plan["passes"] is None:
+            if rm is not None and plan["passes"] is None:
+                plan = dict(plan)
+            return plan
+        rep = [rm.index(pr) for pr in range(B)]            # representative logical row of every physical row
+        plan = dict(plan)
+        plan["passes"] = [[None if rows[l] is None else rows[l].remap(rm, l) for l in rep] for rows in plan["passes"]]
+        if "ref_rows" in plan:
+            plan["ref_rows"] = [rm[plan["ref_rows"][l]] for l in rep]
+        return plan
 
     def _call_list(self, H, W):
         """(is_cross, place, S, heads) of every attention call in execution order."""
@@ -218,7 +244,7 @@ class HipUNet:
             return None
         fps = []
         for is_cross, place, S, heads in self._call_list(H, W):
-            plan = c.plan(self.hook, is_cross, place, B, S, heads, self.device)
+            plan = self._plan(is_cross, place, B, S, heads)
             if plan["passes"] is None:
                 fps.append(0)
                 continue
@@ -265,7 +291,7 @@ class HipUNet:
         scale = D ** -0.5
         if c is None:
             return ops.attention(q, k, vt, t.heads, scale, None, Sk=Sk, C=t.C)
-        plan = c.plan(self.hook, is_cross, place, B, S, t.heads, self.device)
+        plan = self._plan(is_cross, place, B, S, t.heads)
         if plan["kind"] == "shared_kv":
             rr = plan["ref_rows"]
             kc = k[..., :t.C] if k.shape[-1] != t.C else k

@@ -81,7 +81,7 @@ typedef struct ffn_attn_entry {
     const uint8_t* qsel;    /* per-query selector [S] or NULL (=1): allowed(q,k) = (kmask[k]!=0) == (qsel[q]!=0) */
     int flags;              /* FFN_ATT_HEAD_RULE: mask applies only where (b*heads+head) is even (attention.py:859 vs 761);
                                FFN_ATT_UNIFORM_SEL1/0: the allowed set for sel=1/0 is empty -> uniform over all keys */
-    int pad_;
+    int hr_row;             /* 0: the tiled-head rule uses the OUTPUT row index; k>0: it uses row k-1 (row-deduplicated batches) */
 } ffn_attn_entry;
 typedef struct ffn_attn_desc {
     const void* q;      /* [Bq][S][ldq], head h at column h*D */

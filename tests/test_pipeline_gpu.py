@@ -64,6 +64,7 @@ def test_edit_loops_vs_reference_golden(gpu, graph):
         kw = dict(kw)
         text, gs, eta = kw.pop("guidance_text"), kw.pop("guidance_scale"), kw.pop("eta")
         model = make_pipe(gpu, unet_name, "edit", graph=graph)
+        model.dedup_rows = not graph          # cover both: exact row de-duplication of the CFG batch on (eager) / off (graph)
         img_e, img_r = model.FreeFine_generation(ori_img, ori, coarse, tgt, text, gs, eta, verbose=True, return_ori=True, seed=42,
                                                  return_intermediates=True, **kw)
         dev = traj_dev(model.last_intermediates, g[f"{name}_traj"])
