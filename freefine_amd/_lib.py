@@ -73,6 +73,7 @@ SYMBOLS = {
     "ffn_igemm": (_i, [_vp, _i, C.POINTER(IgemmDesc)]),
     "ffn_attn": (_i, [_vp, _i, C.POINTER(AttnDesc)]),
     "ffn_igemm_variant": (_i, [C.POINTER(IgemmDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ffn_igemm_kernel_name": (_i, [_i, C.POINTER(IgemmDesc), C.c_char_p, _i]),
     "ffn_attn_variant": (_i, [_i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ffn_gn_nchunk": (_i, [_i]),
     "ffn_gn_stats": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),

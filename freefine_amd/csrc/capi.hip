@@ -75,6 +75,7 @@ extern "C" int ffn_device_info(int device, char* name, int name_len) {
 }
 
 // ---- igemm -------------------------------------------------------------------------------------------------------
+static void igemm_plan_for(int dtype, const ffn_igemm_desc& d, int* bm, int* bn, int* splitk);
 static int igemm_stages_env() {
     static const int v = [] {
         const char* e = getenv("FFN_IGEMM_STAGES");     // 0/unset = heuristic, 1 = register-staged legacy loader, 2..4 = LDS ring depth
@@ -83,26 +84,79 @@ static int igemm_stages_env() {
     return v;
 }
 template <typename K>
-static int launch_igemm_kernel(K kern, int lds, hipStream_t s, const ffn_igemm_desc& d, int ntiles, int splitk) {
+static int launch_igemm_kernel(K kern, int lds, hipStream_t s, const ffn_igemm_desc& d, int ntiles, int splitk, int threads = 256) {
     int rc = set_lds(kern, lds);
     if (rc) return rc;
-    LAUNCH(kern, dim3(ntiles, splitk), dim3(256), lds, s, d);
+    LAUNCH(kern, dim3(ntiles, splitk), dim3(threads), lds, s, d);
     return check_launch("igemm");
+}
+static int igemm_waves_env() {
+    static const int v = [] {
+        const char* e = getenv("FFN_IGEMM_WAVES");      // 0/unset = heuristic, 4 or 8 waves per workgroup
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+// ring depth and waves per workgroup for a (tile, split) choice.  Measured on MI355X (tools/bench_kernels.py): occupancy beats
+// prefetch depth for these compiler-scheduled loops -- 2 workgroups/CU with a 2-deep ring win over 1 workgroup/CU with a 3-4 deep
+// ring by ~35%; on the 128x128 tile 8 waves (4 waves/SIMD) beat 4 waves by 5-30%, and 16 waves win once the K loop is short.
+static void igemm_exec_cfg(int dtype, const ffn_igemm_desc& d, int bm, int bn, int splitk, int* ns, int* nw) {
+    const int kstage = dtype == FFN_F32 ? 32 : 64;
+    const int nk = ((d.K + kstage - 1) / kstage + splitk - 1) / splitk;    // K stages per workgroup
+    *ns = igemm_stages_env();
+    *nw = igemm_waves_env();
+    if (*ns == 0) *ns = 2;
+    if (*nw == 0) *nw = (bm == 128 && bn == 128 && !d.conv && nk <= 24) ? 16 : 8;
+    if (*ns > 2 && nk < 3) *ns = 2;
+    if (bm == 64) *nw = 4;
+    if (bm == 128 && bn == 64 && *nw > 8) *nw = 8;
+    if (*ns == 1) *nw = 4;
+}
+extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d, char* buf, int len) {
+    REQUIRE(d && buf && len > 0, "igemm_kernel_name: null argument");
+    int bm, bn, sk, ns, nw;
+    igemm_plan_for(dtype, *d, &bm, &bn, &sk);
+    igemm_exec_cfg(dtype, *d, bm, bn, sk, &ns, &nw);
+    const char* t = dtype == FFN_F32 ? "float" : "bf16";
+    const char* swap = (d->flags & FFN_IG_OUT_TRANSPOSED) ? "false" : "true";
+    if (ns == 1) snprintf(buf, len, "void igemm_kernel<%s, %d, %d, %d, %s>(ffn_igemm_desc)", t, bm, bn, d->conv ? 1 : 0, swap);
+    else {
+        const int nwm = nw == 16 ? 4 : (nw == 8 ? (bn == 64 ? 4 : 2) : 2), nwn = nw / nwm;
+        snprintf(buf, len, "void igemm_glds_kernel<%s, %d, %d, %d, %s, %d, %d, %d>(ffn_igemm_desc)", t, bm, bn, d->conv ? 1 : 0, swap, ns, nwm, nwn);
+    }
+    return FFN_OK;
 }
 template <typename T, int BM, int BN, int AMODE, bool SWAP>
 static int launch_igemm(hipStream_t s, const ffn_igemm_desc& d, int splitk) {
     constexpr int stage = (BM + BN) * 128;
-    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
-    const int kstage = sizeof(T) == 4 ? 32 : 64;
-    const int nk = ((d.K + kstage - 1) / kstage + splitk - 1) / splitk;    // K stages per workgroup
-    int ns = igemm_stages_env();
-    if (ns == 0) ns = 2;    // measured: 2 workgroups/CU with a 2-deep ring beat 1 workgroup/CU with a 3-4 deep ring by ~35%
-    if (ns > 2 && nk < 3) ns = 2;
-    int rc;
-    if (ns == 1) rc = launch_igemm_kernel(igemm_kernel<T, BM, BN, AMODE, SWAP>, 2 * stage, s, d, ntm * ntn, splitk);
-    else if (ns == 3) rc = launch_igemm_kernel(igemm_glds_kernel<T, BM, BN, AMODE, SWAP, 3>, 3 * stage, s, d, ntm * ntn, splitk);
-    else if (ns >= 4) rc = launch_igemm_kernel(igemm_glds_kernel<T, BM, BN, AMODE, SWAP, 4>, 4 * stage, s, d, ntm * ntn, splitk);
-    else rc = launch_igemm_kernel(igemm_glds_kernel<T, BM, BN, AMODE, SWAP, 2>, 2 * stage, s, d, ntm * ntn, splitk);
+    const int ntiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+    int ns, nw;
+    igemm_exec_cfg(sizeof(T) == 4 ? FFN_F32 : FFN_BF16, d, BM, BN, splitk, &ns, &nw);
+    int rc = FFN_OK;
+    bool done = false;
+    if constexpr (BM == 128 && BN == 128) {
+        if (nw == 8 && ns >= 2) {   // 8 waves (2x4) on the 128x128 tile: 2 waves/SIMD from ONE workgroup, so a deep ring fits the LDS
+            if (ns == 2) rc = launch_igemm_kernel(igemm_glds_kernel<T, BM, BN, AMODE, SWAP, 2, 2, 4>, 2 * stage, s, d, ntiles, splitk, 512);
+            else if (ns == 3) rc = launch_igemm_kernel(igemm_glds_kernel<T, BM, BN, AMODE, SWAP, 3, 2, 4>, 3 * stage, s, d, ntiles, splitk, 512);
+            else rc = launch_igemm_kernel(igemm_glds_kernel<T, BM, BN, AMODE, SWAP, 4, 2, 4>, 4 * stage, s, d, ntiles, splitk, 512);
+            done = true;
+        } else if (nw == 16) {   // experiment: 16 waves (4x4), 32x32 per wave
+            rc = launch_igemm_kernel(igemm_glds_kernel<T, BM, BN, AMODE, SWAP, 2, 4, 4>, 2 * stage, s, d, ntiles, splitk, 1024);
+            done = true;
+        }
+    }
+    if constexpr (BM == 128 && BN == 64) {
+        if (nw >= 8) {           // 8 waves (4x2), 32x32 per wave
+            rc = launch_igemm_kernel(igemm_glds_kernel<T, BM, BN, AMODE, SWAP, 2, 4, 2>, 2 * stage, s, d, ntiles, splitk, 512);
+            done = true;
+        }
+    }
+    if (!done) {
+        if (ns == 1) rc = launch_igemm_kernel(igemm_kernel<T, BM, BN, AMODE, SWAP>, 2 * stage, s, d, ntiles, splitk);
+        else if (ns == 3) rc = launch_igemm_kernel(igemm_glds_kernel<T, BM, BN, AMODE, SWAP, 3>, 3 * stage, s, d, ntiles, splitk);
+        else if (ns >= 4) rc = launch_igemm_kernel(igemm_glds_kernel<T, BM, BN, AMODE, SWAP, 4>, 4 * stage, s, d, ntiles, splitk);
+        else rc = launch_igemm_kernel(igemm_glds_kernel<T, BM, BN, AMODE, SWAP, 2>, 2 * stage, s, d, ntiles, splitk);
+    }
     if (rc || splitk == 1) return rc;
     const long nq = (long)d.M * (d.N / 4);
     LAUNCH(igemm_splitk_reduce_kernel<T>, dim3(grid_for(nq)), dim3(256), 0, s, d, splitk);

@@ -25,11 +25,9 @@ enum { IG_OUT_SILU = FFN_IG_OUT_SILU, IG_OUT_F32 = FFN_IG_OUT_F32, IG_GEGLU = FF
 typedef ffn_igemm_desc IgemmParams;
 
 // epilogue shared by the igemm kernels: acc[i][j] is the 16x16 fragment (i, j) of this wave's (BM/2) x (BN/2) sub-tile
-template <typename T, int BM, int BN, bool SWAP>
-__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[BM / 32][BN / 32], int m0, int n0, int wm, int wn,
-                                               int l15, int g) {
-    constexpr int WM = BM / 2, WN = BN / 2;
-    constexpr int FM = WM / 16, FN = WN / 16;
+// (mbase, nbase) = global row / column of the wave's sub-tile
+template <typename T, int FM, int FN, bool SWAP>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[FM][FN], int mbase, int nbase, int l15, int g) {
     // ---- epilogue --------------------------------------------------------------------------------
     T* __restrict__ outT = reinterpret_cast<T*>(p.out);
     float* __restrict__ outF = reinterpret_cast<float*>(p.out);
@@ -42,10 +40,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
         float* __restrict__ slab = reinterpret_cast<float*>(p.ws) + (long)blockIdx.y * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const int m = m0 + wm * WM + i * 16 + l15;
+            const int m = mbase + i * 16 + l15;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int n = n0 + wn * WN + j * 16 + 4 * g;
+                const int n = nbase + j * 16 + 4 * g;
                 if (m < p.M && n < p.N) {
                     float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     store4(slab + (long)m * p.N + n, v);
@@ -59,10 +57,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
         if (p.flags & IG_GEGLU) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int m = m0 + wm * WM + i * 16 + l15;
+                const int m = mbase + i * 16 + l15;
 #pragma unroll
                 for (int j = 0; j < FN; j += 2) {
-                    const int nh = n0 + wn * WN + j * 16 + 4 * g;  // packed column of the hidden half
+                    const int nh = nbase + j * 16 + 4 * g;  // packed column of the hidden half
                     if (m < p.M && nh < p.N) {
                         float v[4];
 #pragma unroll
@@ -74,7 +72,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
                             }
                             v[r] = h * gelu_erf(gt);
                         }
-                        const int no = (n0 + wn * WN) / 2 + (j / 2) * 16 + 4 * g;
+                        const int no = (nbase) / 2 + (j / 2) * 16 + 4 * g;
                         store4(outT + (long)m * p.ldo + no, v);
                     }
                 }
@@ -82,11 +80,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
         } else {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int m = m0 + wm * WM + i * 16 + l15;
+                const int m = mbase + i * 16 + l15;
                 const int bb = m / p.rows_per_batch;
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
-                    const int n = n0 + wn * WN + j * 16 + 4 * g;
+                    const int n = nbase + j * 16 + 4 * g;
                     if (m < p.M && n < p.N) {
                         float v[4];
 #pragma unroll
@@ -115,10 +113,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
         // lane holds C[m = ..+4g+r][n = ..+l15]: four consecutive rows of one column -> transposed store
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const int mb = m0 + wm * WM + i * 16 + 4 * g;
+            const int mb = mbase + i * 16 + 4 * g;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int n = n0 + wn * WN + j * 16 + l15;
+                const int n = nbase + j * 16 + l15;
                 if (n >= p.N) continue;
                 float v[4];
 #pragma unroll
@@ -297,7 +295,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         __syncthreads();
     }
 
-    igemm_epilogue<T, BM, BN, SWAP>(p, acc, m0, n0, wm, wn, l15, g);
+    igemm_epilogue<T, FM, FN, SWAP>(p, acc, m0 + wm * WM, n0 + wn * WN, l15, g);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -313,13 +311,16 @@ __device__ __attribute__((aligned(16))) const uint32_t g_zero_chunk[4] = {0, 0, 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <typename T, int BM, int BN, int AMODE, bool SWAP, int NS = 2>   // NS = LDS ring depth (stages in flight = NS-1)
-__global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p) {
+// NS = LDS ring depth (NS-1 stages in flight), NWM x NWN = wave grid over the BM x BN tile (4 or 8 waves)
+template <typename T, int BM, int BN, int AMODE, bool SWAP, int NS = 2, int NWM = 2, int NWN = 2>
+__global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmParams p) {
     constexpr int EPC = DT<T>::EPC;
     constexpr int BKE = 8 * EPC;  // K elements per stage (128 bytes)
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int NW = NWM * NWN;
+    constexpr int WM = BM / NWM, WN = BN / NWN;
     constexpr int FM = WM / 16, FN = WN / 16;
-    constexpr int NA = BM / 32, NB = BN / 32;  // wave-instructions (8 rows each) per wave per stage
+    constexpr int NA = BM / (8 * NW), NB = BN / (8 * NW);  // wave-instructions (8 rows each) per wave per stage
+    static_assert(NA >= 1 && NB >= 1 && FM >= 1 && FN >= 1, "tile too small for this wave grid");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                    // [NS][BM][128]
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int l15 = lane & 15, g = lane >> 4;
 
     const int ntn = (p.N + BN - 1) / BN;
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p) {
     bool a_ok[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int m = m0 + 8 * wave + 32 * i + lrow;
+        const int m = m0 + 8 * (wave + NW * i) + lrow;
         a_ok[i] = m < p.M;
         if (AMODE == AMODE_DENSE) {
             a_base[i] = (long)m * p.lda;
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p) {
     bool b_ok[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int n = n0 + 8 * wave + 32 * i + lrow;
+        const int n = n0 + 8 * (wave + NW * i) + lrow;
         b_ok[i] = n < p.N;
         b_base[i] = (long)n * p.Kpad;
     }
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const char* src = (a_ok[i] && kin) ? reinterpret_cast<const char*>(Ag + a_base[i] + kk) : zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * BM * 128 + (8 * wave + 32 * i) * 128), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * BM * 128 + (8 * (wave + NW * i)) * 128), 16, 0, 0);
             }
         } else {
             const int tap = kk / p.Cin, ci = kk - tap * p.Cin;
@@ -389,13 +390,13 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p) {
                 yy >>= p.upsample;
                 xx >>= p.upsample;
                 const char* src = inb ? reinterpret_cast<const char*>(Ag + (a_base[i] + (long)yy * p.Win + xx) * p.Cin + ci) : zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * BM * 128 + (8 * wave + 32 * i) * 128), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * BM * 128 + (8 * (wave + NW * i)) * 128), 16, 0, 0);
             }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const char* src = (b_ok[i] && kin) ? reinterpret_cast<const char*>(Wg + b_base[i] + kk) : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + buf * BN * 128 + (8 * wave + 32 * i) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + buf * BN * 128 + (8 * (wave + NW * i)) * 128), 16, 0, 0);
         }
     };
 
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p) {
         compute(buf);
         buf = (buf + 1 == NS) ? 0 : buf + 1;
     }
-    igemm_epilogue<T, BM, BN, SWAP>(p, acc, m0, n0, wm, wn, l15, g);
+    igemm_epilogue<T, FM, FN, SWAP>(p, acc, m0 + wm * WM, n0 + wn * WN, l15, g);
 }
 
 // split-K finish: out[m, n..n+3] = epilogue(sum_s slab[s][m][n..n+3])  (same epilogue as the SWAP path of igemm_kernel)

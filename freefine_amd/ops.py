@@ -71,15 +71,20 @@ def _timed(name, flops, nbytes, fn):
     return rc
 
 
+def _attn_name(q, dp, qf, Dh):
+    kt = 32 if (q.dtype == torch.float32 and dp == 160) else 64
+    occ = 2 if (q.dtype == torch.bfloat16 and dp == 64) else 1
+    return f"void attn_kernel<{_tname(q)}, {dp}, {qf}, {kt}, {occ}>(ffn_attn_desc)"
+
+
 def _tname(t):
     return "float" if t.dtype == torch.float32 else "bf16"
 
 
 def _igemm_name(lib, x, d):
-    bm, bn = CT.c_int(), CT.c_int()
-    lib.ffn_igemm_variant(CT.byref(d), CT.byref(bm), CT.byref(bn))
-    swap = "false" if (d.flags & L.IG_OUT_TRANSPOSED) else "true"
-    return f"void igemm_kernel<{_tname(x)}, {bm.value}, {bn.value}, {d.conv}, {swap}>(ffn_igemm_desc)"
+    buf = CT.create_string_buffer(160)
+    lib.ffn_igemm_kernel_name(_dt(x), CT.byref(d), buf, 160)
+    return buf.value.decode()
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -124,10 +129,11 @@ WS_BYTES = 96 << 20
 
 
 def _workspace(device):
-    """one fp32 scratch buffer per device for split-K partial slabs (stream-ordered reuse: all launches share one stream)"""
-    ws = _WS.get(device)
+    """fp32 scratch for split-K partial slabs, one per (device, stream): reuse is ordered by the stream"""
+    key = (device, torch.cuda.current_stream().cuda_stream)     # one buffer per stream: launches on different streams may overlap
+    ws = _WS.get(key)
     if ws is None:
-        ws = _WS[device] = torch.empty(WS_BYTES // 4, dtype=torch.float32, device=device)
+        ws = _WS[key] = torch.empty(WS_BYTES // 4, dtype=torch.float32, device=device)
     return ws
 
 def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, rows_per_batch=None, silu=False,
@@ -261,7 +267,7 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
         dp, qf = CT.c_int(), CT.c_int()
         lib.ffn_attn_variant(_dt(q), Dh, CT.byref(dp), CT.byref(qf))
         esz = q.element_size()
-        L.check(_timed(f"void attn_kernel<{_tname(q)}, {dp.value}, {qf.value}>(ffn_attn_desc)", 4.0 * nterms * S * Sk * Cq,
+        L.check(_timed(_attn_name(q, dp.value, qf.value, Dh), 4.0 * nterms * S * Sk * Cq,
                        esz * nterms * (S * Cq + 2 * Sk * Cq) + esz * Bo * S * Cq,
                        lambda: lib.ffn_attn(_stream(), _dt(q), CT.byref(d))), "ffn_attn")
     return out

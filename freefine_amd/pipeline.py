@@ -52,6 +52,7 @@ class FreeFinePipeline:
         self.controller = None
         self.method_type = None
         self.noise_device = "cpu"
+        self._gen = None
         self.dedup_rows = True      # exact: identical (latent, text) rows of the CFG batch are evaluated once
 
     # ------------------------------------------------------------------------------------------------------------
@@ -101,6 +102,20 @@ class FreeFinePipeline:
     def to(self, device=None, *a, **k):
         return self
 
+    def share(self):
+        """a sibling pipeline over the same weights (see HipUNet.share) for running independent edits concurrently on
+        separate HIP streams; give it its own controller with register_attention_control*."""
+        other = FreeFinePipeline(self.unet.share(), self.vae, self.tokenizer, self.text_encoder,
+                                 DDIMScheduler.from_config(self.scheduler.config), self.device)
+        other.noise_device, other.dedup_rows = self.noise_device, self.dedup_rows
+        return other
+
+    def _seed(self, seed):
+        """seed_everything(seed) (model.py:1018) + a pipeline-local CPU generator seeded identically: the DDPM noise is drawn
+        from the local generator (same mt19937 stream as the global one would give), so concurrent pipelines do not interleave."""
+        seed_everything(seed)
+        self._gen = torch.Generator().manual_seed(seed)
+
     def enable_attention_slicing(self, *a, **k):     # accepted and ignored: the fused kernels never materialise scores
         pass
 
@@ -148,6 +163,8 @@ class FreeFinePipeline:
         m_f = m_host.float().reshape(-1).to(self.device)
         om_f = (1 - m_host).float().reshape(-1).to(self.device)
         c_dirm = [((1 - a_prev - s ** 2) ** 0.5).item() for s in stds]
+        if generator is None:
+            generator = self._gen if self.noise_device == "cpu" else None
         if eta > 0 and noise is None:
             if self.noise_device == "cpu":
                 noise = torch.randn(model_output.shape, generator=generator, dtype=torch.float32).to(self.device)
@@ -622,7 +639,7 @@ class FreeFinePipeline:
                             local_perturbation=True, verbose=True, return_ori=False, seed=42, draw_mask=None,
                             return_intermediates=False, use_auto_draw=False, cons_area=None, reduce_inp_artifacts=False, end_scale=0.5):
         assert method_type in self._METHODS, f"check method type f{method_type}, which is not in {self._METHODS}"
-        seed_everything(seed)
+        self._seed(seed)
         ori_mask, target_mask = self.mask_reduce_dim(ori_mask), self.mask_reduce_dim(target_mask)
         if draw_mask is not None:
             draw_mask = self.mask_reduce_dim(draw_mask)
@@ -640,7 +657,7 @@ class FreeFinePipeline:
                                        start_step=25, share_attn=True, method_type="tca", local_text_edit=True, local_perturbation=True,
                                        verbose=True, seed=42, return_intermediates=False, end_scale=0.5, latent_blended=False,
                                        blend_range=(0, 40)):
-        seed_everything(seed)
+        self._seed(seed)
         ori_mask = self.mask_reduce_dim(ori_mask)
         _, inverted = self.DDIM_inversion_func(img=ori_img, mask=ori_mask, prompt="", num_step=num_step, start_step=start_step,
                                                ref_img=None, verbose=verbose)
@@ -660,7 +677,7 @@ class FreeFinePipeline:
         """model.py:1051-1086.  The reference forwards `use_auto_draw` to a callee without that parameter (TypeError as
         released); it is dropped here so the entry point works."""
         assert method_type in self._METHODS, f"check method type f{method_type}, which is not in {self._METHODS}"
-        seed_everything(seed)
+        self._seed(seed)
         ori_mask_lists = [self.mask_reduce_dim(m) for m in ori_mask_lists]
         tgt_mask_lists = [self.mask_reduce_dim(m) for m in tgt_mask_lists]
         inverted = self.DDIM_inversion_func_compose(img=coarse_input, compose_imgs=img_lists, prompt="", num_step=num_step,

@@ -34,6 +34,7 @@ class HipUNet:
         self._text_bufs = {}
         self.use_graph = False
         self._row_map = None
+        self._plan_cache = {}
         self._pack(state)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -129,12 +130,26 @@ class HipUNet:
         self.t_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.cg_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
 
+    _INSTANCE_STATE = ("hook", "controller", "_graphs", "_text_bufs", "use_graph", "_row_map", "_plan_cache", "t_dev", "cg_dev")
+
+    def share(self):
+        """a second executor over the SAME packed weights with its own controller hook, device scalars, static buffers and
+        graphs -- lets two edits run concurrently on two HIP streams (independent GeoBench cases) without doubling HBM use."""
+        other = object.__new__(HipUNet)
+        other.__dict__.update({k: v for k, v in self.__dict__.items() if k not in self._INSTANCE_STATE})
+        other.hook, other.controller = "edit", None
+        other._graphs, other._text_bufs, other._plan_cache = {}, {}, {}
+        other.use_graph, other._row_map = self.use_graph, None
+        other.t_dev, other.cg_dev = torch.zeros_like(self.t_dev), torch.zeros_like(self.cg_dev)
+        return other
+
     # ------------------------------------------------------------------------------------------------------------
     # reference-API surface
     # ------------------------------------------------------------------------------------------------------------
     def set_attention_control(self, hook, controller):
         self.hook, self.controller = hook, controller
         self._graphs.clear()
+        self._plan_cache.clear()
 
     def to(self, *a, **k):
         return self
@@ -238,10 +253,34 @@ class HipUNet:
                 h, w = 2 * h, 2 * w
         return out
 
+    def _ctrl_key(self, B, H, W):
+        """everything a forward's attention plans depend on (masks by identity + in-place version)"""
+        c = self.controller
+        mv = tuple((m.data_ptr(), m._version) if torch.is_tensor(m) else None
+                   for m in (c.fg_retain_mask, c.fg_ref_mask, c.local_edit_region, c.src_masks, c.tgt_masks))
+        return (self.hook, B, H, W, self._row_map, c.use_tca, c.use_style_align, c.local_edit, c.method, tuple(c.layer_idx),
+                tuple(c.tca_scope), tuple(c.style_align_scope), c.cur_att_layer, c.prompt_length, c._mask_epoch, mv)
+
     def _plan_all(self, B, H, W):
         c = self.controller
         if c is None:
             return None
+        key = self._ctrl_key(B, H, W)
+        hit = self._plan_cache.get(key)
+        if hit is not None:                      # nothing the plans depend on changed: only advance the counters
+            c.cur_step += 1 if c.cur_att_layer == 0 else 0
+            if c.cur_att_layer != 0:
+                for _ in range(self.num_attention_calls):
+                    c._tick()
+            return hit
+        fp = self._plan_all_slow(B, H, W)
+        if len(self._plan_cache) > 64:
+            self._plan_cache.clear()
+        self._plan_cache[key] = fp
+        return fp
+
+    def _plan_all_slow(self, B, H, W):
+        c = self.controller
         fps = []
         for is_cross, place, S, heads in self._call_list(H, W):
             plan = self._plan(is_cross, place, B, S, heads)

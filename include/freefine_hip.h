@@ -64,6 +64,8 @@ typedef struct ffn_igemm_desc {
 int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
 /* which tile (BM x BN) ffn_igemm dispatches for this problem -- lets a profiler name the kernel instantiation */
 int ffn_igemm_variant(const ffn_igemm_desc* d, int* bm, int* bn);
+/* the kernel instantiation ffn_igemm launches for this problem, spelled like rocprofv3's kernel trace */
+int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d, char* buf, int len);
 
 /* ---- multi-pass masked attention (the FreeFine attention modulation) -----------------------------------------
  * out[b,q,h,:] = sum_p w_p(b) * wq_p[q] * softmax_k(scale*<Q[qrow_p(b),q,h],K[kvrow_p(b),k,h]> + mask_p(q,k)) V[kvrow_p(b),k,h]
