@@ -53,6 +53,7 @@ class FreeFinePipeline:
         self.method_type = None
         self.noise_device = "cpu"
         self._gen = None
+        self._mask_dev = None
         self.dedup_rows = True      # exact: identical (latent, text) rows of the CFG batch are evaluated once
 
     # ------------------------------------------------------------------------------------------------------------
@@ -157,11 +158,12 @@ class FreeFinePipeline:
             stds, masked = [std] * rows, [1] * rows
         if mask is None:
             masked = [0] * rows
-            m_host = torch.ones(x.shape[-2:], dtype=torch.float32)
-        else:
-            m_host = mask.detach().cpu()
-        m_f = m_host.float().reshape(-1).to(self.device)
-        om_f = (1 - m_host).float().reshape(-1).to(self.device)
+            mask = torch.ones(x.shape[-2:], dtype=torch.float32)
+        mkey = (mask.data_ptr(), mask._version, tuple(mask.shape), mask.dtype)
+        if self._mask_dev is None or self._mask_dev[0] != mkey or self._mask_dev[1] is not mask:
+            m_host = mask.detach().cpu()                # (1 - mask) in the mask's own dtype: uint8 wrap-around preserved
+            self._mask_dev = (mkey, mask, m_host.float().reshape(-1).to(self.device), (1 - m_host).float().reshape(-1).to(self.device))
+        m_f, om_f = self._mask_dev[2], self._mask_dev[3]
         c_dirm = [((1 - a_prev - s ** 2) ** 0.5).item() for s in stds]
         if generator is None:
             generator = self._gen if self.noise_device == "cpu" else None
@@ -173,6 +175,15 @@ class FreeFinePipeline:
         return ops.ddim_ctrl_step(model_output.contiguous(), x.contiguous(), noise if eta > 0 else None, m_f, om_f,
                                   ((1 - a_t) ** 0.5).item(), (a_t ** 0.5).item(), (a_prev ** 0.5).item(), ((1 - a_prev) ** 0.5).item(),
                                   c_dirm, [s.item() for s in stds], masked, want_pred_x0=True)
+
+    def _predraw_noise(self, n, shape, eta):
+        """the n randn draws of the loop (model.py:185-188), in order, from the same generator, uploaded ONCE: nothing else
+        consumes the generator inside the loop, so the values are identical to drawing one per step."""
+        if eta <= 0 or n <= 0:
+            return None
+        if self.noise_device != "cpu":
+            return torch.randn((n,) + tuple(shape), device=self.device, dtype=torch.float32)
+        return torch.stack([torch.randn(tuple(shape), generator=self._gen, dtype=torch.float32) for _ in range(n)]).to(self.device)
 
     def linear_param(self, t, t1, t0, t2, end_scale=0.5):
         """model.py:438-455"""
@@ -318,6 +329,9 @@ class FreeFinePipeline:
         cfg_f = self._mask_f(completion_mask_cfg) if local_edit_text else None
         row_map, lat_rows, txt_rows = self._cfg_row_map(text, 2)
         text_phys = text[txt_rows].contiguous() if row_map is not None else text
+        lat_idx = torch.tensor(lat_rows, device=self.device) if row_map is not None else None
+        noises = self._predraw_noise(num_inference_steps - start_step, (2,) + tuple(latents.shape[1:]), eta)
+        var_mask = local_var_reg if local_perturbation else torch.ones_like(local_var_reg)
         for i, t in enumerate(self.scheduler.timesteps):
             if i < start_step:
                 continue
@@ -333,11 +347,10 @@ class FreeFinePipeline:
             if row_map is None:
                 noise_pred = self.unet(torch.cat([latents] * 2), t, encoder_hidden_states=text)
             else:
-                noise_pred = self.unet(latents[lat_rows], t, encoder_hidden_states=text_phys, row_map=row_map)
+                noise_pred = self.unet(latents.index_select(0, lat_idx), t, encoder_hidden_states=text_phys, row_map=row_map)
             eu, ec = noise_pred.chunk(2, dim=0)
             noise_pred = ops.cfg_masked(eu.contiguous(), ec.contiguous(), cfg_f, guidance_scale)
-            mask = local_var_reg if local_perturbation else torch.ones_like(local_var_reg)
-            latents = self.ctrl_step(noise_pred, t, latents, mask, eta=eta)[0]
+            latents = self.ctrl_step(noise_pred, t, latents, var_mask, eta=eta, noise=None if noises is None else noises[i - start_step])[0]
             latents_list.append(latents)
         image = self.latent2image(latents, return_type="pt")
         return (image, latents_list) if return_intermediates else (image, None)
@@ -367,6 +380,9 @@ class FreeFinePipeline:
         cfg_f = self._mask_f(local_cfg_reg) if local_text_edit else None
         row_map, lat_rows, txt_rows = self._cfg_row_map(text, 2)
         text_phys = text[txt_rows].contiguous() if row_map is not None else text
+        lat_idx = torch.tensor(lat_rows, device=self.device) if row_map is not None else None
+        noises = self._predraw_noise(num_inference_steps - start_step, (2,) + tuple(latents.shape[1:]), eta)
+        var_mask = local_var_reg if local_perturbation else torch.ones_like(local_var_reg)
         for i, t in enumerate(self.scheduler.timesteps):
             if i < start_step:
                 continue
@@ -381,11 +397,10 @@ class FreeFinePipeline:
             if row_map is None:
                 noise_pred = self.unet(torch.cat([latents] * 2), t, encoder_hidden_states=text)
             else:
-                noise_pred = self.unet(latents[lat_rows], t, encoder_hidden_states=text_phys, row_map=row_map)
+                noise_pred = self.unet(latents.index_select(0, lat_idx), t, encoder_hidden_states=text_phys, row_map=row_map)
             eu, ec = noise_pred.chunk(2, dim=0)
             noise_pred = ops.cfg_masked(eu.contiguous(), ec.contiguous(), cfg_f, guidance_scale)
-            mask = local_var_reg if local_perturbation else torch.ones_like(local_var_reg)
-            latents = self.ctrl_step(noise_pred, t, latents, mask, eta=eta)[0]
+            latents = self.ctrl_step(noise_pred, t, latents, var_mask, eta=eta, noise=None if noises is None else noises[i - start_step])[0]
             latents_list.append(latents[0])
         image = self.latent2image(latents, return_type="pt")
         return (image, latents_list) if return_intermediates else (image, None)
@@ -410,6 +425,8 @@ class FreeFinePipeline:
         latents_list = [latents]
         start_step = num_inference_steps - num_actual_inference_steps
         cfg_f = self._mask_f(cfg_masks_tensor) if local_edit_text else None
+        noises = self._predraw_noise(num_inference_steps - start_step, (1,) + tuple(latents.shape[1:]), eta)
+        var_mask = local_var_reg if local_perturbation else torch.ones_like(local_var_reg)
         for i, t in enumerate(self.scheduler.timesteps):
             if i < start_step:
                 continue
@@ -425,8 +442,8 @@ class FreeFinePipeline:
             noise_pred = self.unet(torch.cat([latents, latents[0][None]]), t, encoder_hidden_states=text)
             eu, ec = noise_pred[0][None].contiguous(), noise_pred[-1][None].contiguous()
             noise_pred = ops.cfg_masked(eu, ec, cfg_f, guidance_scale)
-            mask = local_var_reg if local_perturbation else torch.ones_like(local_var_reg)
-            latents = self.ctrl_step(noise_pred, t, latents[0][None].contiguous(), mask, eta=eta)[0]
+            latents = self.ctrl_step(noise_pred, t, latents[0][None].contiguous(), var_mask, eta=eta,
+                                     noise=None if noises is None else noises[i - start_step])[0]
             latents_list.append(latents[0])
         image = self.latent2image(latents, return_type="pt")[0]
         return (image, latents_list) if return_intermediates else (image, None)

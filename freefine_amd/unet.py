@@ -35,6 +35,7 @@ class HipUNet:
         self.use_graph = False
         self._row_map = None
         self._plan_cache = {}
+        self._row_idx = {}
         self._pack(state)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -130,7 +131,7 @@ class HipUNet:
         self.t_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.cg_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
 
-    _INSTANCE_STATE = ("hook", "controller", "_graphs", "_text_bufs", "use_graph", "_row_map", "_plan_cache", "t_dev", "cg_dev")
+    _INSTANCE_STATE = ("hook", "controller", "_graphs", "_text_bufs", "use_graph", "_row_map", "_plan_cache", "_row_idx", "t_dev", "cg_dev")
 
     def share(self):
         """a second executor over the SAME packed weights with its own controller hook, device scalars, static buffers and
@@ -138,7 +139,7 @@ class HipUNet:
         other = object.__new__(HipUNet)
         other.__dict__.update({k: v for k, v in self.__dict__.items() if k not in self._INSTANCE_STATE})
         other.hook, other.controller = "edit", None
-        other._graphs, other._text_bufs, other._plan_cache = {}, {}, {}
+        other._graphs, other._text_bufs, other._plan_cache, other._row_idx = {}, {}, {}, {}
         other.use_graph, other._row_map = self.use_graph, None
         other.t_dev, other.cg_dev = torch.zeros_like(self.t_dev), torch.zeros_like(self.cg_dev)
         return other
@@ -215,7 +216,10 @@ class HipUNet:
     def _expand(self, eps):
         if self._row_map is None:
             return eps
-        return eps[list(self._row_map)]
+        idx = self._row_idx.get(self._row_map)
+        if idx is None:                                   # device-side index: no per-step host->device copy / sync
+            idx = self._row_idx[self._row_map] = torch.tensor(self._row_map, device=self.device)
+        return eps.index_select(0, idx)
 
     def _plan(self, is_cross, place, B, S, heads):
         """controller plan for the logical batch, translated to the physical (deduplicated) rows"""
