@@ -187,16 +187,16 @@ static void igemm_plan_for(int dtype, const ffn_igemm_desc& d, int* bm, int* bn,
         *bn = 64;
     } else if (!d.conv && !(d.flags & FFN_IG_GEGLU) && d.M >= 128 && (!can_split(d) || t12864 >= 128)) {
         *bm = 128; *bn = 64;      // dense Linear layers (short K, memory/latency bound): measured 5-25% faster than 128x128
-    } else if (can_split(d) && d.N >= 128 && d.M >= 96 && t128 < 256) {
-        *bm = 128; *bn = 128;
-    } else if (d.N > 64 && (t128 >= 384 || (d.N % 128 == 0 && t128 >= 256))) { *bm = 128; *bn = 128; }
-    else if (t12864 >= 256 || d.M >= 4096) { *bm = 128; *bn = 64; }
-    else { *bm = 64; *bn = 64; }
+    } else if (d.N > 64 && (t128 >= 256 || (can_split(d) && d.M > 512 && d.N >= 128))) {
+        *bm = 128; *bn = 128;     // measured (tools/bench_kernels.py): from M = 1024 up, 128x128 + split-K beats 128x64 without it
+    } else if (t12864 >= 256 || d.M >= 4096 || (can_split(d) && d.M >= 96 && d.N >= 64)) {
+        *bm = 128; *bn = 64;      // M <= 512: half the K slices (and slab traffic) of 128x128 for the same number of workgroups
+    } else { *bm = 64; *bn = 64; }
     if (can_split(d)) {
         const int kstage = dtype == FFN_F32 ? 32 : 64;
         const int nk = (d.K + kstage - 1) / kstage;
         const long tiles = (long)((d.M + *bm - 1) / *bm) * ((d.N + *bn - 1) / *bn);
-        int s = d.splitk > 1 ? d.splitk : (tiles >= 256 ? 1 : (int)((512 + tiles - 1) / tiles));
+        int s = d.splitk > 1 ? d.splitk : (tiles >= 224 ? 1 : (int)((448 + tiles - 1) / tiles));
         if (d.splitk <= 1 && s > nk / 6) s = nk / 6;            // keep >= 6 K stages per slice
         const long per = (long)d.M * d.N * 4;
         if ((long)s * per > d.ws_bytes) s = (int)(d.ws_bytes / per);
