@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libfreefine_hip.so")
 
 FFN_F32, FFN_BF16 = 0, 1
 IG_OUT_SILU, IG_OUT_F32, IG_GEGLU, IG_OUT_TRANSPOSED = 1, 2, 4, 8
-ATT_MAXP, ATT_MAXB = 4, 8
+ATT_MAXP, ATT_MAXB = 4, 16
 ATT_HEAD_RULE, ATT_UNIFORM_SEL1, ATT_UNIFORM_SEL0 = 1, 2, 4
 
 

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
     constexpr int EPC = DT<T>::EPC;
     constexpr int SZ = sizeof(T);
     constexpr int NT = KT / 16;                 // 16-key fragments per tile
-    constexpr int KROW = DP * SZ + 16;          // K tile row stride (bytes), +16 B pad against bank conflicts
+    constexpr bool KSWZ = (DP * SZ == 128);     // 128-byte K rows: XOR-swizzled chunks (conflict-free ds_read_b128, like igemm)
+    constexpr int KROW = KSWZ ? 128 : DP * SZ + 16;   // otherwise +16 B row padding (2-way conflicts on some lane groups)
     constexpr int VROW = KT * SZ + 16;          // V^T tile row stride
     constexpr int DCH = DP / EPC;               // 16-byte chunks per K row
     constexpr int DSL = DP * SZ / 64;           // 64-byte d-slabs (MFMA k-substeps of QK^T)
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
             for (int i = 0; i < NKC; ++i) {
                 const int cid = tid + 256 * i;
                 const int key = cid / DCH, c = cid - key * DCH;
-                *reinterpret_cast<u32x4*>(Ks + buf * KBUF + key * KROW + c * 16) = rk[i];
+                *reinterpret_cast<u32x4*>(Ks + buf * KBUF + key * KROW + ((KSWZ ? (c ^ (key & 7)) : c) << 4)) = rk[i];
             }
 #pragma unroll
             for (int i = 0; i < NVC; ++i) {
@@ -195,7 +196,8 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
             for (int s = 0; s < DSL; ++s) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const u32x4 ka = *reinterpret_cast<const u32x4*>(Kb + (t * 16 + l15) * KROW + (4 * s + g) * 16);
+                    const int krow = t * 16 + l15;
+                    const u32x4 ka = *reinterpret_cast<const u32x4*>(Kb + krow * KROW + ((KSWZ ? ((4 * s + g) ^ (krow & 7)) : (4 * s + g)) << 4));
 #pragma unroll
                     for (int f = 0; f < QF; ++f) DT<T>::mma(ka, qf[f][s], st[t][f]);
                 }

@@ -277,7 +277,8 @@ template <typename T, int DP, int QF, int KT = 64, int OCC = 1>
 static int launch_attn(hipStream_t s, const ffn_attn_desc& d) {
     constexpr int SZ = sizeof(T);
     // double-buffered K and V^T tiles + the per-wave multi-pass accumulator
-    constexpr int lds = 2 * (KT * (DP * SZ + 16) + DP * (KT * SZ + 16)) + 4 * (DP / 16) * QF * 64 * 16;
+    constexpr int krow = (DP * SZ == 128) ? 128 : DP * SZ + 16;
+    constexpr int lds = 2 * (KT * krow + DP * (KT * SZ + 16)) + 4 * (DP / 16) * QF * 64 * 16;
     static_assert(lds <= 160 * 1024, "attention tile does not fit the 160 KiB LDS");
     auto kern = attn_kernel<T, DP, QF, KT, OCC>;
     static bool lds_set = false;

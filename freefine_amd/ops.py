@@ -231,10 +231,17 @@ class AttnEntrySpec:
         return AttnEntrySpec(row_map[self.q_row], row_map[self.kv_row], self.w_const, self.w_slope, self.wq, self.kmask, self.qsel,
                              self.flags, logical_row if self.hr_row is None else self.hr_row)
 
+    def shifted(self, base, logical_row):
+        """the same term inside an image-batched launch: this image's physical rows start at `base`; the tiled-head rule
+        (attention.py:859 vs 761) keeps using the row index the image would have had in its own batch"""
+        return AttnEntrySpec(self.q_row + base, self.kv_row + base, self.w_const, self.w_slope, self.wq, self.kmask, self.qsel,
+                             self.flags, logical_row if self.hr_row is None else self.hr_row)
+
 
 def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=None, Bo=None, C=None):
     """q: [Bq,S,C]; k: [Bk,Sk,C]; vt: [Bk,C,ldvt] (V transposed).  passes: list (per pass) of lists (per output
-    row) of AttnEntrySpec or None (= skipped).  passes=None -> plain attention, row b uses its own K/V."""
+    row) of AttnEntrySpec or None (= skipped).  passes=None -> plain attention, row b uses its own K/V.
+    More than FFN_ATT_MAXB output rows are issued as several launches over row ranges (entries name absolute Q/KV rows)."""
     lib = L.load()
     Bq, S, _ = q.shape
     Cq = C if C is not None else q.shape[2]          # q / k may be column views of a wider [B,S,ld] buffer
@@ -245,31 +252,38 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
     Bo = Bo if Bo is not None else len(passes[0])
     if out is None:
         out = torch.empty(Bo, S, Cq, dtype=q.dtype, device=q.device)
-    d = L.AttnDesc()
-    d.q, d.k, d.vt, d.out, d.w_dev = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), _p(w_dev)
-    d.Bo, d.S, d.Sk, d.heads, d.D = Bo, S, Sk, heads, Dh
-    d.ldq, d.ldk, d.ldvt, d.ldo = q.stride(1), k.stride(1), vt.stride(1), Cq
-    d.scale, d.npass = scale, len(passes)
-    for p, rows in enumerate(passes):
+    for rows in passes:
         assert len(rows) == Bo
-        for b, sp in enumerate(rows):
-            e = d.e[p * L.ATT_MAXB + b]
-            if sp is None:
-                e.w_const = e.w_slope = 0.0
-                continue
-            e.q_row, e.kv_row, e.w_const, e.w_slope = sp.q_row, sp.kv_row, sp.w_const, sp.w_slope
-            e.wq, e.kmask, e.qsel, e.flags = _p(sp.wq), _p(sp.kmask), _p(sp.qsel), sp.flags
-            e.hr_row = 0 if sp.hr_row is None else sp.hr_row + 1
-    if _PROF is None:
-        L.check(lib.ffn_attn(_stream(), _dt(q), CT.byref(d)), "ffn_attn")
-    else:
-        nterms = sum(1 for rows in passes for sp in rows if sp is not None and (sp.w_const != 0.0 or sp.w_slope != 0.0))
-        dp, qf = CT.c_int(), CT.c_int()
-        lib.ffn_attn_variant(_dt(q), Dh, CT.byref(dp), CT.byref(qf))
-        esz = q.element_size()
-        L.check(_timed(_attn_name(q, dp.value, qf.value, Dh), 4.0 * nterms * S * Sk * Cq,
-                       esz * nterms * (S * Cq + 2 * Sk * Cq) + esz * Bo * S * Cq,
-                       lambda: lib.ffn_attn(_stream(), _dt(q), CT.byref(d))), "ffn_attn")
+    esz = q.element_size()
+    for b0 in range(0, Bo, L.ATT_MAXB):
+        nb = min(L.ATT_MAXB, Bo - b0)
+        d = L.AttnDesc()
+        d.q, d.k, d.vt, d.w_dev = q.data_ptr(), k.data_ptr(), vt.data_ptr(), _p(w_dev)
+        d.out = out.data_ptr() + b0 * S * Cq * esz
+        d.Bo, d.S, d.Sk, d.heads, d.D = nb, S, Sk, heads, Dh
+        d.ldq, d.ldk, d.ldvt, d.ldo = q.stride(1), k.stride(1), vt.stride(1), Cq
+        d.scale, d.npass = scale, len(passes)
+        for p, rows in enumerate(passes):
+            for b in range(nb):
+                sp = rows[b0 + b]
+                e = d.e[p * L.ATT_MAXB + b]
+                if sp is None:
+                    e.w_const = e.w_slope = 0.0
+                    continue
+                e.q_row, e.kv_row, e.w_const, e.w_slope = sp.q_row, sp.kv_row, sp.w_const, sp.w_slope
+                e.wq, e.kmask, e.qsel, e.flags = _p(sp.wq), _p(sp.kmask), _p(sp.qsel), sp.flags
+                # the tiled-head rule defaults to the OUTPUT row index, which a row-range launch shifts by b0: pin it
+                hr = sp.hr_row if sp.hr_row is not None else (b0 + b if b0 else None)
+                e.hr_row = 0 if hr is None else hr + 1
+        if _PROF is None:
+            L.check(lib.ffn_attn(_stream(), _dt(q), CT.byref(d)), "ffn_attn")
+        else:
+            nterms = sum(1 for rows in passes for sp in rows[b0:b0 + nb] if sp is not None and (sp.w_const != 0.0 or sp.w_slope != 0.0))
+            dp, qf = CT.c_int(), CT.c_int()
+            lib.ffn_attn_variant(_dt(q), Dh, CT.byref(dp), CT.byref(qf))
+            L.check(_timed(_attn_name(q, dp.value, qf.value, Dh), 4.0 * nterms * S * Sk * Cq,
+                           esz * nterms * (S * Cq + 2 * Sk * Cq) + esz * nb * S * Cq,
+                           lambda: lib.ffn_attn(_stream(), _dt(q), CT.byref(d))), "ffn_attn")
     return out
 
 

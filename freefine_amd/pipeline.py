@@ -53,7 +53,8 @@ class FreeFinePipeline:
         self.method_type = None
         self.noise_device = "cpu"
         self._gen = None
-        self._mask_dev = None
+        self._mask_dev = {}
+        self._batch_ctrls = {}
         self.dedup_rows = True      # exact: identical (latent, text) rows of the CFG batch are evaluated once
 
     # ------------------------------------------------------------------------------------------------------------
@@ -160,10 +161,13 @@ class FreeFinePipeline:
             masked = [0] * rows
             mask = torch.ones(x.shape[-2:], dtype=torch.float32)
         mkey = (mask.data_ptr(), mask._version, tuple(mask.shape), mask.dtype)
-        if self._mask_dev is None or self._mask_dev[0] != mkey or self._mask_dev[1] is not mask:
+        ent = self._mask_dev.get(mkey)
+        if ent is None or ent[0] is not mask:
+            if len(self._mask_dev) >= 32:
+                self._mask_dev.clear()
             m_host = mask.detach().cpu()                # (1 - mask) in the mask's own dtype: uint8 wrap-around preserved
-            self._mask_dev = (mkey, mask, m_host.float().reshape(-1).to(self.device), (1 - m_host).float().reshape(-1).to(self.device))
-        m_f, om_f = self._mask_dev[2], self._mask_dev[3]
+            ent = self._mask_dev[mkey] = (mask, m_host.float().reshape(-1).to(self.device), (1 - m_host).float().reshape(-1).to(self.device))
+        m_f, om_f = ent[1], ent[2]
         c_dirm = [((1 - a_prev - s ** 2) ** 0.5).item() for s in stds]
         if generator is None:
             generator = self._gen if self.noise_device == "cpu" else None
@@ -669,6 +673,136 @@ class FreeFinePipeline:
             cons_area=cons_area, use_auto_draw=use_auto_draw, end_scale=end_scale, reduce_inp_artifacts=reduce_inp_artifacts)
         self.last_intermediates = inter
         return (edit_img, ref_img) if return_ori else edit_img
+
+    # ------------------------------------------------------------------------------------------------------------
+    # image-level batching: K independent FreeFine_generation edits as ONE image-major batch
+    # ------------------------------------------------------------------------------------------------------------
+    def _controllers_for_batch(self, K):
+        """the registered controller plus K-1 siblings with the same layer selection; cached so that their static mask
+        vectors (and therefore the captured graphs of the batched forward) survive from one batch to the next"""
+        from .attention import Attention_Modulator
+        base = self.controller
+        assert isinstance(base, Attention_Modulator), "register_attention_control(model, Attention_Modulator(...)) first"
+        ctrls = self._batch_ctrls.get(K)
+        if ctrls is None or ctrls[0] is not base:
+            ctrls = [base]
+            for _ in range(K - 1):
+                c = Attention_Modulator()
+                c.layer_idx, c.num_att_layers, c.LOW_RESOURCE = list(base.layer_idx), base.num_att_layers, base.LOW_RESOURCE
+                ctrls.append(c)
+            self._batch_ctrls[K] = ctrls
+        return ctrls
+
+    @torch.no_grad()
+    def FreeFine_generation_batch(self, cases, guidance_scale, eta, end_step=10, num_step=50, start_step=25, share_attn=True,
+                                  method_type="tca", local_perturbation=True, verbose=True, return_ori=False, seeds=42,
+                                  return_intermediates=False, end_scale=0.5):
+        """K = len(cases) independent FreeFine_generation edits (model.py:1640-1700 each) sharing schedule, method and
+        guidance scale, each with its own images, masks, prompt and seed, evaluated together: every UNet forward of the
+        inversion runs 2K rows and every forward of the guided sampling K*Bp rows (Bp = 3 with row dedup, else 4), image-major.
+        Rows of different images never interact (attention reference rows, GroupNorm and the scheduler are per row / per
+        image), so result i equals FreeFine_generation(**cases[i], seed=seeds[i]) up to fp32 summation order where the GEMM
+        split-K choice depends on the batch size.
+        cases: dicts with ori_img, ori_mask, coarse_input, target_mask, guidance_text, draw_mask (+ optional use_auto_draw,
+        cons_area, reduce_inp_artifacts).  Returns a list of edited images (or (edit, ref) pairs with return_ori)."""
+        assert method_type in self._METHODS, f"check method type f{method_type}, which is not in {self._METHODS}"
+        assert guidance_scale > 1.0, "USING THIS MODULE CFG Must > 1.0"
+        K = len(cases)
+        seeds = [seeds] * K if isinstance(seeds, int) else list(seeds)
+        single, hook = self.controller, self.unet.hook
+        ctrls = self._controllers_for_batch(K)
+        self.unet.hook, self.unet.controller = hook, (ctrls if K > 1 else single)      # no graph flush: graphs are keyed by the plans
+        try:
+            return self._generation_batch(cases, ctrls, seeds, guidance_scale, eta, end_step, num_step, start_step, share_attn,
+                                          method_type, local_perturbation, return_ori, return_intermediates, end_scale)
+        finally:
+            self.controller = single
+            self.unet.controller = single
+
+    def _generation_batch(self, cases, ctrls, seeds, guidance_scale, eta, end_step, num_step, start_step, share_attn, method_type,
+                          local_perturbation, return_ori, return_intermediates, end_scale):
+        K = len(cases)
+        seed_everything(seeds[0])
+        gens = [torch.Generator().manual_seed(s) for s in seeds]
+        red = self.mask_reduce_dim
+        # ---- inversion of [coarse_i, ori_i] for every image: one 2K-row batch (model.py:1341-1388 + 816-925)
+        source = torch.from_numpy(np.concatenate([np.stack([c["coarse_input"], self.resize_img(c["ori_img"], size=[512, 512])])
+                                                  for c in cases]))
+        for c in ctrls:
+            c.reset()
+        _, inverted = self.invert(source, "", guidance_scale=1.0, num_inference_steps=num_step,
+                                  num_actual_inference_steps=num_step - start_step, return_intermediates=True)
+        for c in ctrls:
+            c.reset()
+        # ---- per-image masks, controller state, text rows (model.py:1012-1118, 476-526)
+        init = inverted[-1]
+        refer = inverted[::-1]
+        cfg_f, var_masks, texts = [], [], []
+        for case, c in zip(cases, ctrls):
+            full_h, full_w = case["coarse_input"].shape[:2]
+            draw = case.get("draw_mask")
+            fg, shifted_t, ori_t, cfg_m, var_m = self.prepare_various_mask(
+                red(case["target_mask"]), red(case["ori_mask"]), None if draw is None else red(draw), full_h, full_w, init,
+                use_auto_draw=case.get("use_auto_draw", False), cons_area=case.get("cons_area"),
+                reduce_inp_artifacts=case.get("reduce_inp_artifacts", False))
+            cfg_m = self._nearest(cfg_m, (init.shape[2], init.shape[3]))
+            c.fg_retain_mask, c.fg_retain_mask_st2, c.fg_ref_mask, c.local_edit_region = fg, shifted_t, ori_t, fg
+            c.reset()
+            c.log_mask = False
+            self.controller = c
+            self._configure_method(method_type, share_attn)
+            c.local_edit = True                               # see Details_Preserving_regeneration: the reference never turns it off
+            cfg_f.append(self._mask_f(cfg_m))
+            var_masks.append(var_m if local_perturbation else torch.ones_like(var_m))
+            texts.append(torch.cat([self._encode_text(["", ""]), self._encode_text([case["guidance_text"], ""])], dim=0))
+        self.controller = ctrls[0]
+        maps = [self._cfg_row_map(t, 2) for t in texts]
+        if all(m[0] is not None and m[0] == maps[0][0] for m in maps):
+            row_map, lat_rows, txt_rows = maps[0]
+        else:                                                 # images disagree on which CFG rows coincide: evaluate all four
+            row_map, lat_rows, txt_rows = None, [0, 1, 0, 1], [0, 1, 2, 3]
+        Bp = len(lat_rows)
+        text_phys = torch.cat([t[txt_rows] for t in texts], dim=0).contiguous()
+        lat_idx = torch.tensor([2 * i + r for i in range(K) for r in lat_rows], device=self.device)
+        self.scheduler.set_timesteps(num_step)
+        n_act = num_step - start_step
+        shape2 = (2,) + tuple(init.shape[1:])
+        noises = []
+        for g in gens:
+            self._gen = g
+            noises.append(self._predraw_noise(n_act, shape2, eta))
+        latents = init.clone()                                # [2K,4,h,w]: rows (edit_i, ref_i)
+        lat_v = latents.view(K, 2, *init.shape[1:])
+        # like the reference's latents_list (model.py:585-616) the recorded entries ALIAS the live latents: the reference row of
+        # entry j is overwritten in place by step j+1's `latents[1:] = ref_latent`
+        inter = [[latents[2 * i:2 * i + 2]] for i in range(K)] if return_intermediates else None
+        for i, t in enumerate(self.scheduler.timesteps):
+            if i < start_step:
+                continue
+            lat_v[:, 1] = refer[i - start_step + 1].view(K, 2, *init.shape[1:])[:, 1]
+            for c in ctrls:
+                if method_type == "tca":
+                    c.context_guidance = self.linear_param(i, start_step, end_step, num_step, end_scale=end_scale)
+                elif method_type == "mmsa_es" and i >= end_step:
+                    c.use_tca = False
+            eps = self.unet(latents.index_select(0, lat_idx), t, encoder_hidden_states=text_phys, row_map=row_map)
+            eps = eps.view(K, 4, *init.shape[1:])
+            new = torch.empty_like(latents)
+            for k in range(K):
+                e = ops.cfg_masked(eps[k, :2].contiguous(), eps[k, 2:].contiguous(), cfg_f[k], guidance_scale)
+                new[2 * k:2 * k + 2] = self.ctrl_step(e, t, latents[2 * k:2 * k + 2], var_masks[k], eta=eta,
+                                                      noise=None if noises[k] is None else noises[k][i - start_step])[0]
+                if inter is not None:
+                    inter[k].append(new[2 * k:2 * k + 2])
+            latents = new
+            lat_v = latents.view(K, 2, *init.shape[1:])
+        for c in ctrls:
+            c.reset()
+        images = self.latent2image(latents, return_type="pt")
+        to_u8 = lambda im: (im.permute(1, 2, 0).detach().cpu().numpy() * 255).astype(np.uint8)
+        self.last_intermediates = inter
+        return [(to_u8(images[2 * k]), to_u8(images[2 * k + 1])) if return_ori else to_u8(images[2 * k]) for k in range(K)]
+
 
     def FreeFine_background_generation(self, ori_img, ori_mask, guidance_text, guidance_scale, eta, end_step=10, num_step=50,
                                        start_step=25, share_attn=True, method_type="tca", local_text_edit=True, local_perturbation=True,

@@ -148,9 +148,15 @@ class HipUNet:
     # reference-API surface
     # ------------------------------------------------------------------------------------------------------------
     def set_attention_control(self, hook, controller):
+        """controller: one Attention_Modulator, or a list of them = an IMAGE-BATCHED forward: the batch holds len(list)
+        independent edits, image-major (image i owns physical rows [i*Bp, (i+1)*Bp)); each controller plans its own rows."""
         self.hook, self.controller = hook, controller
         self._graphs.clear()
         self._plan_cache.clear()
+
+    def _ctrls(self):
+        c = self.controller
+        return [] if c is None else (list(c) if isinstance(c, (list, tuple)) else [c])
 
     def to(self, *a, **k):
         return self
@@ -193,21 +199,23 @@ class HipUNet:
         B = sample.shape[0]
         self._row_map = tuple(row_map) if row_map is not None else None
         self.t_dev.fill_(float(timestep))
-        c = self.controller
-        if c is not None and c.context_guidance is not None:
-            self.cg_dev.fill_(float(c.context_guidance))
+        ctrls = self._ctrls()
+        assert not ctrls or B % len(ctrls) == 0, f"batch {B} is not a multiple of the {len(ctrls)} batched images"
+        if ctrls and ctrls[0].context_guidance is not None:
+            assert all(c.context_guidance == ctrls[0].context_guidance for c in ctrls), "batched images share one schedule"
+            self.cg_dev.fill_(float(ctrls[0].context_guidance))
         text_kv = self.prepare_text(enc)
         if not self.use_graph:
             return self._expand(self._run(sample, text_kv))
         # graph mode: plan every attention call first (this also refreshes the controller's static mask vectors and
         # advances its counters exactly as an eager forward would); the plans' fingerprint is part of the graph key
-        state = (c.cur_att_layer, c.cur_step) if c is not None else None
+        state = [(c.cur_att_layer, c.cur_step) for c in ctrls]
         fp = self._plan_all(B, sample.shape[2], sample.shape[3])
-        sig = (B, tuple(sample.shape), tuple(enc.shape), fp, self._row_map)
+        sig = (B, tuple(sample.shape), tuple(enc.shape), fp, self._row_map, len(ctrls))
         g = self._graphs.get(sig)
         if g is None:
-            if c is not None:
-                c.cur_att_layer, c.cur_step = state
+            for c, st in zip(ctrls, state):
+                c.cur_att_layer, c.cur_step = st
             g = self._capture(sample, text_kv, sig)
         g["x"].copy_(sample)
         g["graph"].replay()
@@ -216,19 +224,18 @@ class HipUNet:
     def _expand(self, eps):
         if self._row_map is None:
             return eps
-        idx = self._row_idx.get(self._row_map)
+        rm, K = self._row_map, max(1, len(self._ctrls()))
+        idx = self._row_idx.get((rm, K))
         if idx is None:                                   # device-side index: no per-step host->device copy / sync
-            idx = self._row_idx[self._row_map] = torch.tensor(self._row_map, device=self.device)
+            Bp = eps.shape[0] // K
+            idx = self._row_idx[(rm, K)] = torch.tensor([i * Bp + r for i in range(K) for r in rm], device=self.device)
         return eps.index_select(0, idx)
 
-    def _plan(self, is_cross, place, B, S, heads):
-        """controller plan for the logical batch, translated to the physical (deduplicated) rows"""
-        c = self.controller
+    def _plan_one(self, c, is_cross, place, B, S, heads):
+        """one controller's plan for its logical batch, translated to its physical (deduplicated) rows"""
         rm = self._row_map
         plan = c.plan(self.hook, is_cross, place, len(rm) if rm is not None else B, S, heads, self.device)
         if rm is None or plan["passes"] is None:
-            if rm is not None and plan["passes"] is None:
-                plan = dict(plan)
             return plan
         rep = [rm.index(pr) for pr in range(B)]            # representative logical row of every physical row
         plan = dict(plan)
@@ -236,6 +243,34 @@ class HipUNet:
         if "ref_rows" in plan:
             plan["ref_rows"] = [rm[plan["ref_rows"][l]] for l in rep]
         return plan
+
+    def _plan(self, is_cross, place, B, S, heads):
+        """plan of this attention call for the whole physical batch.  Image-batched forwards: every image's controller plans
+        its own Bp rows; the tables are concatenated with the image's row offset, the tiled-head rule pinned to the row index
+        the image would have had alone (attention.py:859 vs 761 depend on b*heads+head)."""
+        ctrls = self._ctrls()
+        if len(ctrls) == 1:
+            return self._plan_one(ctrls[0], is_cross, place, B, S, heads)
+        K = len(ctrls)
+        Bp = B // K
+        plans = [self._plan_one(c, is_cross, place, Bp, S, heads) for c in ctrls]
+        if all(p["passes"] is None for p in plans):
+            return plans[0]
+        assert len({p["kind"] for p in plans}) == 1, "batched images must take the same attention branch kind"
+        rm = self._row_map
+        rep = [rm.index(pr) for pr in range(Bp)] if rm is not None else list(range(Bp))
+        npass = max(len(p["passes"]) for p in plans if p["passes"] is not None)
+        merged = [[] for _ in range(npass)]
+        for i, plan in enumerate(plans):
+            ps = plan["passes"] if plan["passes"] is not None else [[ops.AttnEntrySpec(b, b) for b in range(Bp)]]
+            for p in range(npass):
+                rows = ps[p] if p < len(ps) else [None] * Bp
+                merged[p] += [None if e is None else e.shifted(i * Bp, rep[pr]) for pr, e in enumerate(rows)]
+        out = dict(kind=plans[0]["kind"], passes=merged, needs_cg=any(p["needs_cg"] for p in plans),
+                   branch="+".join(sorted({p.get("branch", "") for p in plans})))
+        if any("ref_rows" in p for p in plans):
+            out["ref_rows"] = [i * Bp + r for i, p in enumerate(plans) for r in p.get("ref_rows", list(range(Bp)))]
+        return out
 
     def _call_list(self, H, W):
         """(is_cross, place, S, heads) of every attention call in execution order."""
@@ -259,23 +294,26 @@ class HipUNet:
 
     def _ctrl_key(self, B, H, W):
         """everything a forward's attention plans depend on (masks by identity + in-place version)"""
-        c = self.controller
-        mv = tuple((m.data_ptr(), m._version) if torch.is_tensor(m) else None
-                   for m in (c.fg_retain_mask, c.fg_ref_mask, c.local_edit_region, c.src_masks, c.tgt_masks))
-        return (self.hook, B, H, W, self._row_map, c.use_tca, c.use_style_align, c.local_edit, c.method, tuple(c.layer_idx),
-                tuple(c.tca_scope), tuple(c.style_align_scope), c.cur_att_layer, c.prompt_length, c._mask_epoch, mv)
+        key = [self.hook, B, H, W, self._row_map]
+        for c in self._ctrls():
+            mv = tuple((m.data_ptr(), m._version) if torch.is_tensor(m) else None
+                       for m in (c.fg_retain_mask, c.fg_ref_mask, c.local_edit_region, c.src_masks, c.tgt_masks))
+            key.append((id(c), c.use_tca, c.use_style_align, c.local_edit, c.method, tuple(c.layer_idx), tuple(c.tca_scope),
+                        tuple(c.style_align_scope), c.cur_att_layer, c.prompt_length, c._mask_epoch, mv))
+        return tuple(key)
 
     def _plan_all(self, B, H, W):
-        c = self.controller
-        if c is None:
+        ctrls = self._ctrls()
+        if not ctrls:
             return None
         key = self._ctrl_key(B, H, W)
         hit = self._plan_cache.get(key)
         if hit is not None:                      # nothing the plans depend on changed: only advance the counters
-            c.cur_step += 1 if c.cur_att_layer == 0 else 0
-            if c.cur_att_layer != 0:
-                for _ in range(self.num_attention_calls):
-                    c._tick()
+            for c in ctrls:
+                c.cur_step += 1 if c.cur_att_layer == 0 else 0
+                if c.cur_att_layer != 0:
+                    for _ in range(self.num_attention_calls):
+                        c._tick()
             return hit
         fp = self._plan_all_slow(B, H, W)
         if len(self._plan_cache) > 64:
@@ -284,14 +322,13 @@ class HipUNet:
         return fp
 
     def _plan_all_slow(self, B, H, W):
-        c = self.controller
         fps = []
         for is_cross, place, S, heads in self._call_list(H, W):
             plan = self._plan(is_cross, place, B, S, heads)
             if plan["passes"] is None:
                 fps.append(0)
                 continue
-            rows = tuple(tuple(None if e is None else (e.q_row, e.kv_row, e.w_const, e.w_slope, e.flags,
+            rows = tuple(tuple(None if e is None else (e.q_row, e.kv_row, e.w_const, e.w_slope, e.flags, e.hr_row,
                                                        0 if e.wq is None else e.wq.data_ptr(),
                                                        0 if e.kmask is None else e.kmask.data_ptr(),
                                                        0 if e.qsel is None else e.qsel.data_ptr()) for e in r) for r in plan["passes"])
@@ -299,13 +336,13 @@ class HipUNet:
         return (self.hook, tuple(fps))
 
     def _capture(self, sample, text_kv, sig):
-        c = self.controller
-        state = (c.cur_att_layer, c.cur_step) if c is not None else None
+        ctrls = self._ctrls()
+        state = [(c.cur_att_layer, c.cur_step) for c in ctrls]
         x_static = sample.clone()
         # warm-up outside capture (lazy module loading, LDS opt-ins, first upload of mask vectors), counters restored after
         self._run(x_static, text_kv)
-        if c is not None:
-            c.cur_att_layer, c.cur_step = state
+        for c, st in zip(ctrls, state):
+            c.cur_att_layer, c.cur_step = st
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
@@ -329,10 +366,9 @@ class HipUNet:
         return ops.conv3x3(h, r.c2[0], r.c2[1], B, H, W, r.cout, residual=x)
 
     def _attention(self, t, is_cross, place, q, k, vt, ldq_view, B, S, Sk):
-        c = self.controller
         D = t.C // t.heads
         scale = D ** -0.5
-        if c is None:
+        if self.controller is None:
             return ops.attention(q, k, vt, t.heads, scale, None, Sk=Sk, C=t.C)
         plan = self._plan(is_cross, place, B, S, t.heads)
         if plan["kind"] == "shared_kv":

@@ -73,7 +73,7 @@ int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d, char* buf, int len
  * style_align_share_attention, mask_attention, get_attention_scores, get_cross_hidden_state and the prepare_*_mask
  * builders (src/utils/attention.py:774-1432) plus the plain branch of ca_forward (attention.py:394-404). */
 #define FFN_ATT_MAXP 4
-#define FFN_ATT_MAXB 8
+#define FFN_ATT_MAXB 16
 enum { FFN_ATT_HEAD_RULE = 1, FFN_ATT_UNIFORM_SEL1 = 2, FFN_ATT_UNIFORM_SEL0 = 4 };
 typedef struct ffn_attn_entry {
     int q_row, kv_row;      /* batch rows supplying Q and K/V for this (pass, output row) */

@@ -204,6 +204,49 @@ def test_attention_tca_edit(gpu, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_image_batched_rows(gpu, dtype):
+    """image-batched launch: 5 images x 4 rows = 20 output rows (> FFN_ATT_MAXB -> issued as row ranges); every image uses its
+    own masks, reference rows offset by the image base, and the tiled-head rule pinned to the row index INSIDE the image."""
+    from freefine_amd import ops
+    from freefine_amd._lib import ATT_HEAD_RULE, ATT_MAXB
+    g = torch.Generator().manual_seed(77)
+    K, Bp, S, heads, D = 5, 4, 96, 3, 64
+    assert K * Bp > ATT_MAXB
+    Cc = heads * D
+    q = rnd((K * Bp, S, Cc), dtype, gpu, g)
+    k = rnd((K * Bp, S, Cc), dtype, gpu, g)
+    v = rnd((K * Bp, S, Cc), dtype, gpu, g)
+    vt = ops.transpose(v)
+    cg = 0.6
+    cg_dev = torch.tensor([cg], dtype=torch.float32, device=gpu)
+    scale = D ** -0.5
+    ref_rows = [1, 1, 3, 3]
+    srcs = [(torch.rand(S, generator=g) > 0.5).to(torch.uint8) for _ in range(K)]
+    tgts = [(torch.rand(S, generator=g) > 0.5).to(torch.uint8) for _ in range(K)]
+    p_ref, p_self = [], []
+    for i in range(K):
+        sg, tg = srcs[i].to(gpu), tgts[i].to(gpu)
+        for b in range(Bp):
+            p_ref.append(ops.AttnEntrySpec(b, ref_rows[b], 0.0, 1.0, kmask=sg, qsel=tg, flags=ATT_HEAD_RULE).shifted(i * Bp, b))
+            p_self.append(ops.AttnEntrySpec(b, b, 1.0, -1.0).shifted(i * Bp, b))
+    out = ops.attention(q, k, vt, heads, scale, [p_ref, p_self], w_dev=cg_dev)
+    qc, kc, vc = q.double().cpu(), k.double().cpu(), v.double().cpu()
+    for i in range(K):
+        for b in range(Bp):
+            allowed = torch.ones(heads, S, S, dtype=torch.bool)
+            for h in range(heads):
+                if (b * heads + h) % 2 == 0:
+                    allowed[h] = (srcs[i][None, :] != 0) == (tgts[i][:, None] != 0)
+            r = ref_attention(qc[i * Bp + b], kc[i * Bp + ref_rows[b]], vc[i * Bp + ref_rows[b]], heads, scale, allowed)
+            s_ = ref_attention(qc[i * Bp + b], kc[i * Bp + b], vc[i * Bp + b], heads, scale)
+            assert relerr(out[i * Bp + b], cg * r + (1 - cg) * s_) < tol(dtype), (i, b)
+    # plain attention over more rows than one launch takes
+    out = ops.attention(q, k, vt, heads, scale)
+    for b in (0, ATT_MAXB - 1, ATT_MAXB, K * Bp - 1):
+        assert relerr(out[b], ref_attention(qc[b], kc[b], vc[b], heads, scale)) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_uniform_and_wq(gpu, dtype):
     """empty allowed set -> uniform softmax over all keys; per-query weights; skipped entries; q_row remap."""
     from freefine_amd import ops

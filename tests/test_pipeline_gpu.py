@@ -74,6 +74,50 @@ def test_edit_loops_vs_reference_golden(gpu, graph):
         assert np.abs(img_r[::4, ::4].astype(int) - g[f"{name}_ref_img"].astype(int)).max() <= 1, name
 
 
+def _batch_cases():
+    ori_img, coarse, img2 = synth_images()
+    ori, tgt, draw, *_ = mask_inputs()
+    from golden_cases import rect_mask
+    ori_b, tgt_b, draw_b = rect_mask(128, 128, 20, 60, 70, 110, 255), rect_mask(128, 128, 30, 70, 50, 90, 255), rect_mask(128, 128, 24, 76, 44, 98, 1)
+    return [dict(ori_img=ori_img, ori_mask=ori, coarse_input=coarse, target_mask=tgt, guidance_text="a cup", draw_mask=draw),
+            dict(ori_img=img2, ori_mask=ori_b, coarse_input=ori_img, target_mask=tgt_b, guidance_text="a dog on grass", draw_mask=draw_b),
+            dict(ori_img=coarse, ori_mask=tgt, coarse_input=img2, target_mask=ori_b, guidance_text="", draw_mask=draw_b)]
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_image_batched_edits_match_single_edits(gpu, graph):
+    """FreeFine_generation_batch: K edits in one image-major batch == the K single-image edits, and image 0
+    (the reference's golden edit_tca_draw inputs) still matches the REFERENCE's golden trajectory.  Two batches: images that
+    agree on the CFG row de-duplication (3 physical rows each) and a mix with an empty prompt (falls back to 4 rows each)."""
+    g = np.load(os.path.join(GOLD, "g5_loops.npz"))
+    name, unet_name, kw = edit_cases()[0]
+    kw = {k: v for k, v in kw.items() if k in ("end_step", "num_step", "start_step", "method_type", "end_scale")}
+    cases, seeds = _batch_cases(), [42, 7, 1234]
+    single = []
+    model = make_pipe(gpu, unet_name, "edit", graph=graph)
+    for c, sd in zip(cases, seeds):
+        img = model.FreeFine_generation(c["ori_img"], c["ori_mask"], c["coarse_input"], c["target_mask"], c["guidance_text"], 7.5, 1.0,
+                                        draw_mask=c["draw_mask"], seed=sd, return_intermediates=True, **kw)
+        single.append((img, [t.clone() for t in model.last_intermediates]))
+    assert traj_dev(single[0][1], g[f"{name}_traj"]) < TOL
+    for sel in ([0, 1], [0, 1, 2]):
+        for rep in range(2 if graph else 1):                       # second pass replays the captured batched graphs
+            imgs = model.FreeFine_generation_batch([cases[i] for i in sel], 7.5, 1.0, seeds=[seeds[i] for i in sel],
+                                                   return_intermediates=True, **kw)
+            for j, i in enumerate(sel):
+                dev = traj_dev(model.last_intermediates[j], [t.cpu().numpy() for t in single[i][1]])
+                print(f"batch {sel} graph={graph} rep={rep} image {i}: latent L-inf vs single-image edit {dev:.2e}")
+                assert dev < 1e-4, (sel, i)
+                assert np.abs(imgs[j].astype(int) - single[i][0].astype(int)).max() <= 1
+            dev = traj_dev(model.last_intermediates[0], g[f"{name}_traj"])
+            assert dev < TOL
+    # the single-image path is intact after batching (controller restored)
+    c = cases[1]
+    img = model.FreeFine_generation(c["ori_img"], c["ori_mask"], c["coarse_input"], c["target_mask"], c["guidance_text"], 7.5, 1.0,
+                                    draw_mask=c["draw_mask"], seed=seeds[1], return_intermediates=True, **kw)
+    assert traj_dev(model.last_intermediates, [t.cpu().numpy() for t in single[1][1]]) < 1e-5
+
+
 def test_bggen_and_compose_vs_reference_golden(gpu):
     g = np.load(os.path.join(GOLD, "g5_loops.npz"))
     ori_img, coarse, img2 = synth_images()
