@@ -112,20 +112,6 @@ static void igemm_exec_cfg(int dtype, const ffn_igemm_desc& d, int bm, int bn, i
     if (bm == 128 && bn == 64 && *nw > 8) *nw = 8;
     if (*ns == 1) *nw = 4;
 }
-extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d, char* buf, int len) {
-    REQUIRE(d && buf && len > 0, "igemm_kernel_name: null argument");
-    int bm, bn, sk, ns, nw;
-    igemm_plan_for(dtype, *d, &bm, &bn, &sk);
-    igemm_exec_cfg(dtype, *d, bm, bn, sk, &ns, &nw);
-    const char* t = dtype == FFN_F32 ? "float" : "bf16";
-    const char* swap = (d->flags & FFN_IG_OUT_TRANSPOSED) ? "false" : "true";
-    if (ns == 1) snprintf(buf, len, "void igemm_kernel<%s, %d, %d, %d, %s>(ffn_igemm_desc)", t, bm, bn, d->conv ? 1 : 0, swap);
-    else {
-        const int nwm = nw == 16 ? 4 : (nw == 8 ? (bn == 64 ? 4 : 2) : 2), nwn = nw / nwm;
-        snprintf(buf, len, "void igemm_glds_kernel<%s, %d, %d, %d, %s, %d, %d, %d>(ffn_igemm_desc)", t, bm, bn, d->conv ? 1 : 0, swap, ns, nwm, nwn);
-    }
-    return FFN_OK;
-}
 template <typename T, int BM, int BN, int AMODE, bool SWAP>
 static int launch_igemm(hipStream_t s, const ffn_igemm_desc& d, int splitk) {
     constexpr int stage = (BM + BN) * 128;
@@ -224,14 +210,189 @@ extern "C" int ffn_attn_variant(int dtype, int D, int* dp, int* qf) {
     return FFN_OK;
 }
 
+
+// ---- bf16 tile configurations and first-use autotuning ------------------------------------------------------------------
+// The SD shapes span M = 4 ... 4M rows and N = 4 ... 10240 columns; which (tile, K-split) wins depends on how the tile count
+// quantises over 256 CUs as much as on the tile's own efficiency (measured, tools/bench_kernels.py: at M = 98304 the 128x320 tile
+// runs the N = 320 convs at 850-1000 TFLOP/s where 128x128 -- 17% of its third column tile wasted -- gives 690-760; 256x256
+// reaches 1190 on N = 1280 but loses 20% on N = 640).  So the first time a problem shape is seen outside stream capture, the
+// few plausible configurations are timed on the caller's stream with the caller's buffers and the winner is cached.
+enum { CFG_64x64, CFG_128x64, CFG_128x128_8, CFG_128x128_16, CFG_256x128, CFG_256x256, CFG_128x320, CFG_COUNT };
+struct IgCfgInfo { int bm, bn, nwm, nwn; };
+static const IgCfgInfo kCfg[CFG_COUNT] = {{64, 64, 2, 2}, {128, 64, 4, 2}, {128, 128, 2, 4}, {128, 128, 4, 4},
+                                          {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 320, 4, 4}};
+struct IgChoice { int cfg, splitk; };
+
+template <int AMODE>
+static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) {
+    const IgCfgInfo& c = kCfg[ch.cfg];
+    const int ntiles = ((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn);
+    const int lds = 2 * (c.bm + c.bn) * 128, threads = 64 * c.nwm * c.nwn;
+    int rc = FFN_OK;
+    switch (ch.cfg) {
+        case CFG_64x64: rc = launch_igemm_kernel(igemm_glds_kernel<bf16, 64, 64, AMODE, true, 2, 2, 2>, lds, s, d, ntiles, ch.splitk, threads); break;
+        case CFG_128x64: rc = launch_igemm_kernel(igemm_glds_kernel<bf16, 128, 64, AMODE, true, 2, 4, 2>, lds, s, d, ntiles, ch.splitk, threads); break;
+        case CFG_128x128_8: rc = launch_igemm_kernel(igemm_glds_kernel<bf16, 128, 128, AMODE, true, 2, 2, 4>, lds, s, d, ntiles, ch.splitk, threads); break;
+        case CFG_128x128_16: rc = launch_igemm_kernel(igemm_glds_kernel<bf16, 128, 128, AMODE, true, 2, 4, 4>, lds, s, d, ntiles, ch.splitk, threads); break;
+        case CFG_256x128: rc = launch_igemm_kernel(igemm_glds_kernel<bf16, 256, 128, AMODE, true, 2, 4, 4>, lds, s, d, ntiles, ch.splitk, threads); break;
+        case CFG_256x256: rc = launch_igemm_kernel(igemm_glds_kernel<bf16, 256, 256, AMODE, true, 2, 4, 4>, lds, s, d, ntiles, ch.splitk, threads); break;
+        case CFG_128x320: rc = launch_igemm_kernel(igemm_glds_kernel<bf16, 128, 320, AMODE, true, 2, 4, 4>, lds, s, d, ntiles, ch.splitk, threads); break;
+        default: return fail(FFN_EINVAL, "igemm: bad configuration %d", ch.cfg);
+    }
+    if (rc || ch.splitk == 1) return rc;
+    const long nq = (long)d.M * (d.N / 4);
+    LAUNCH(igemm_splitk_reduce_kernel<bf16>, dim3(grid_for(nq)), dim3(256), 0, s, d, ch.splitk);
+    return check_launch("igemm_splitk_reduce");
+}
+
+struct TuneKey {
+    int M, N, K, conv, Cin, Hin, Win, stride, upsample, flags, lda, splitk, ptrs;
+    bool operator==(const TuneKey& o) const { return memcmp(this, &o, sizeof(TuneKey)) == 0; }
+};
+struct TuneKeyHash {
+    size_t operator()(const TuneKey& k) const {
+        const int* p = reinterpret_cast<const int*>(&k);
+        size_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < sizeof(TuneKey) / sizeof(int); ++i) h = (h ^ (size_t)(unsigned)p[i]) * 1099511628211ull;
+        return h;
+    }
+};
+static TuneKey tune_key(const ffn_igemm_desc& d) {
+    TuneKey k;
+    memset(&k, 0, sizeof(k));
+    k.M = d.M; k.N = d.N; k.K = d.K; k.conv = d.conv; k.flags = d.flags; k.lda = d.lda; k.splitk = d.splitk;
+    if (d.conv) { k.Cin = d.Cin; k.Hin = d.Hin; k.Win = d.Win; k.stride = d.stride; k.upsample = d.upsample; }
+    k.ptrs = (d.bias ? 1 : 0) | (d.rowbias ? 2 : 0) | (d.residual ? 4 : 0) | (d.ws && d.ws_bytes > 0 ? 8 : 0);
+    return k;
+}
+static std::mutex g_tune_mu;
+static std::unordered_map<TuneKey, IgChoice, TuneKeyHash> g_tuned;
+static bool tune_enabled() {
+    static const bool on = [] { const char* e = getenv("FFN_IGEMM_TUNE"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+// the deterministic rule-based choice (also what f32 parity mode uses): igemm_plan_for + igemm_exec_cfg mapped to a configuration
+static IgChoice heuristic_choice(const ffn_igemm_desc& d) {
+    int bm, bn, sk, ns, nw;
+    igemm_plan_for(FFN_BF16, d, &bm, &bn, &sk);
+    igemm_exec_cfg(FFN_BF16, d, bm, bn, sk, &ns, &nw);
+    int cfg = CFG_64x64;
+    if (bm == 128 && bn == 64) cfg = CFG_128x64;
+    if (bm == 128 && bn == 128) cfg = nw == 16 ? CFG_128x128_16 : CFG_128x128_8;
+    return IgChoice{cfg, sk};
+}
+static int candidates_for(const ffn_igemm_desc& d, IgChoice* out, int cap) {
+    int n = 0;
+    const IgChoice h = heuristic_choice(d);
+    out[n++] = h;
+    const int nk = (d.K + 63) / 64;
+    const long per = (long)d.M * d.N * 4;
+    for (int cfg = 0; cfg < CFG_COUNT; ++cfg) {
+        const IgCfgInfo& c = kCfg[cfg];
+        if (cfg == CFG_128x320 && (d.flags & FFN_IG_GEGLU)) continue;              // odd number of column blocks per wave
+        if (c.bm > 64 && c.bm >= 2 * d.M) continue;                                // tile mostly empty
+        if (c.bn > 64 && c.bn >= 2 * d.N) continue;
+        if (cfg == CFG_64x64 && (long)d.M * d.N > (1l << 22)) continue;
+        const long tiles = (long)((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn);
+        int splits[3] = {1, 0, 0};
+        if (d.splitk > 1) splits[0] = d.splitk;
+        else if (can_split(d)) {
+            for (int t = 0; t < 2; ++t) {
+                int sgo = (int)(((t ? 512 : 256) + tiles / 2) / tiles);
+                if (sgo > nk / 4) sgo = nk / 4;
+                if ((long)sgo * per > d.ws_bytes) sgo = (int)(d.ws_bytes / per);
+                if (sgo >= 2) splits[1 + t] = sgo;
+            }
+            if (splits[2] == splits[1]) splits[2] = 0;
+        }
+        for (int t = 0; t < 3 && n < cap; ++t) {
+            if (!splits[t]) continue;
+            bool dup = false;
+            for (int j = 0; j < n; ++j) dup |= out[j].cfg == cfg && out[j].splitk == splits[t];
+            if (!dup) out[n++] = IgChoice{cfg, splits[t]};
+        }
+    }
+    return n;
+}
+template <int AMODE>
+static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    const bool aliased = d.residual == d.out;        // repeated launches would accumulate: never time such a call
+    const TuneKey key = tune_key(d);
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        auto it = g_tuned.find(key);
+        if (it != g_tuned.end()) return launch_bf16_cfg<AMODE>(s, d, it->second);
+    }
+    if (!tune_enabled() || cap != hipStreamCaptureStatusNone || aliased) return launch_bf16_cfg<AMODE>(s, d, heuristic_choice(d));
+    std::lock_guard<std::mutex> lk(g_tune_mu);       // one tuning at a time
+    IgChoice cand[24];
+    const int nc = candidates_for(d, cand, 24);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return launch_bf16_cfg<AMODE>(s, d, cand[0]);
+    IgChoice best = cand[0];
+    float best_ms = 1e30f;
+    const int reps = 3;
+    for (int i = 0; i < nc; ++i) {
+        int rc = launch_bf16_cfg<AMODE>(s, d, cand[i]);      // warm (LDS opt-in, code load)
+        if (rc) continue;
+        hipEventRecord(e0, s);
+        for (int r = 0; r < reps && !rc; ++r) rc = launch_bf16_cfg<AMODE>(s, d, cand[i]);
+        hipEventRecord(e1, s);
+        if (rc || hipEventSynchronize(e1) != hipSuccess) continue;
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best_ms) { best_ms = ms; best = cand[i]; }
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    g_tuned[key] = best;
+    static const bool verbose = getenv("FFN_IGEMM_TUNE_VERBOSE") != nullptr;
+    if (verbose)
+        fprintf(stderr, "[ffn tune] %s M=%d N=%d K=%d flags=%d -> %dx%d split %d (%.1f us, %d candidates)\n", d.conv ? "conv" : "dense", d.M, d.N,
+                d.K, d.flags, kCfg[best.cfg].bm, kCfg[best.cfg].bn, best.splitk, best_ms * 1e3f / reps, nc);
+    return launch_bf16_cfg<AMODE>(s, d, best);       // the output now holds the winner's result
+}
+static bool tuned_lookup(const ffn_igemm_desc& d, IgChoice* ch) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tuned.find(tune_key(d));
+    if (it == g_tuned.end()) return false;
+    *ch = it->second;
+    return true;
+}
+
+extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d, char* buf, int len) {
+    REQUIRE(d && buf && len > 0, "igemm_kernel_name: null argument");
+    int bm, bn, sk, ns, nw;
+    IgChoice ch;
+    if (dtype == FFN_BF16 && !(d->flags & FFN_IG_OUT_TRANSPOSED)) {      // the tuned (or, untuned, rule-based) bf16 configuration
+        if (!tuned_lookup(*d, &ch)) ch = heuristic_choice(*d);
+        const IgCfgInfo& c = kCfg[ch.cfg];
+        snprintf(buf, len, "void igemm_glds_kernel<bf16, %d, %d, %d, true, 2, %d, %d>(ffn_igemm_desc)", c.bm, c.bn, d->conv ? 1 : 0, c.nwm, c.nwn);
+        return FFN_OK;
+    }
+    igemm_plan_for(dtype, *d, &bm, &bn, &sk);
+    igemm_exec_cfg(dtype, *d, bm, bn, sk, &ns, &nw);
+    const char* t = dtype == FFN_F32 ? "float" : "bf16";
+    const char* swap = (d->flags & FFN_IG_OUT_TRANSPOSED) ? "false" : "true";
+    if (ns == 1) snprintf(buf, len, "void igemm_kernel<%s, %d, %d, %d, %s>(ffn_igemm_desc)", t, bm, bn, d->conv ? 1 : 0, swap);
+    else {
+        const int nwm = nw == 16 ? 4 : (nw == 8 ? (bn == 64 ? 4 : 2) : 2), nwn = nw / nwm;
+        snprintf(buf, len, "void igemm_glds_kernel<%s, %d, %d, %d, %s, %d, %d, %d>(ffn_igemm_desc)", t, bm, bn, d->conv ? 1 : 0, swap, ns, nwm, nwn);
+    }
+    return FFN_OK;
+}
 template <typename T>
 static int dispatch_igemm(hipStream_t s, const ffn_igemm_desc& d) {
     const bool tr = d.flags & FFN_IG_OUT_TRANSPOSED;
     if (d.conv) {
         if (tr) return fail(FFN_EINVAL, "igemm: transposed output is only supported for dense A");
+        if constexpr (sizeof(T) == 2) return tuned_bf16<AMODE_CONV3>(s, d);
         return dispatch_igemm_tile<T, AMODE_CONV3, true>(s, d);
     }
     if (tr) return dispatch_igemm_tile<T, AMODE_DENSE, false>(s, d);
+    if constexpr (sizeof(T) == 2) return tuned_bf16<AMODE_DENSE>(s, d);
     return dispatch_igemm_tile<T, AMODE_DENSE, true>(s, d);
 }
 extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {

@@ -54,12 +54,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
     }
     if (SWAP) {
         // lane holds C[m = ..+l15][n = ..+4g+r], r = 0..3: four consecutive columns of one row
-        if (p.flags & IG_GEGLU) {
+        if ((FN % 2 == 0) && (p.flags & IG_GEGLU)) {      // hidden / gate column blocks come in pairs: even FN only
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int m = mbase + i * 16 + l15;
 #pragma unroll
-                for (int j = 0; j < FN; j += 2) {
+                for (int j = 0; j + 1 < FN; j += 2) {
                     const int nh = nbase + j * 16 + 4 * g;  // packed column of the hidden half
                     if (m < p.M && nh < p.N) {
                         float v[4];
@@ -319,8 +319,11 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
     constexpr int NW = NWM * NWN;
     constexpr int WM = BM / NWM, WN = BN / NWN;
     constexpr int FM = WM / 16, FN = WN / 16;
-    constexpr int NA = BM / (8 * NW), NB = BN / (8 * NW);  // wave-instructions (8 rows each) per wave per stage
-    static_assert(NA >= 1 && NB >= 1 && FM >= 1 && FN >= 1, "tile too small for this wave grid");
+    constexpr int GA = BM / 8, GB = BN / 8;                      // 8-row groups (one wave-instruction each) per stage
+    constexpr int NA = (GA + NW - 1) / NW, NB = (GB + NW - 1) / NW;  // wave-instructions per wave per stage (last one may be idle)
+    static_assert(BM % 16 == 0 && BN % 16 == 0 && BM % NWM == 0 && BN % NWN == 0 && WM % 16 == 0 && WN % 16 == 0, "tile / wave grid mismatch");
+    static_assert(FM >= 1 && FN >= 1, "tile too small for this wave grid");
+    static_assert(NS == 2 || (GA % NW == 0 && GB % NW == 0), "counted vmcnt waits need the same number of loads in every wave");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                    // [NS][BM][128]
@@ -377,6 +380,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
         if (AMODE == AMODE_DENSE) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
+                if (GA % NW != 0 && wave + NW * i >= GA) continue;
                 const char* src = (a_ok[i] && kin) ? reinterpret_cast<const char*>(Ag + a_base[i] + kk) : zero;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * BM * 128 + (8 * (wave + NW * i)) * 128), 16, 0, 0);
             }
@@ -385,6 +389,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
             const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
+                if (GA % NW != 0 && wave + NW * i >= GA) continue;
                 int yy = a_y[i] + ky, xx = a_x[i] + kx;
                 const bool inb = a_ok[i] && kin && yy >= 0 && yy < He && xx >= 0 && xx < We;
                 yy >>= p.upsample;
@@ -395,6 +400,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
+            if (GB % NW != 0 && wave + NW * i >= GB) continue;
             const char* src = (b_ok[i] && kin) ? reinterpret_cast<const char*>(Wg + b_base[i] + kk) : zero;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + buf * BN * 128 + (8 * (wave + NW * i)) * 128), 16, 0, 0);
         }

@@ -381,12 +381,14 @@ def pack_nchw(src, src_rows, CP, dtype, out=None):
     B = len(src_rows)
     if out is None:
         out = torch.empty(B, H * W, CP, dtype=dtype, device=src.device)
-    d = L.PackDesc()
-    d.src, d.dst = src.data_ptr(), out.data_ptr()
-    for i, r in enumerate(src_rows):
-        d.src_row[i] = r
-    d.B, d.Cl, d.CP, d.HW = B, Cl, CP, H * W
-    L.check(lib.ffn_pack_nchw(_stream(), _dt(out), CT.byref(d)), "ffn_pack_nchw")
+    for b0 in range(0, B, 16):                     # the descriptor names up to 16 source rows per launch
+        nb = min(16, B - b0)
+        d = L.PackDesc()
+        d.src, d.dst = src.data_ptr(), out.data_ptr() + b0 * H * W * CP * out.element_size()
+        for i in range(nb):
+            d.src_row[i] = src_rows[b0 + i]
+        d.B, d.Cl, d.CP, d.HW = nb, Cl, CP, H * W
+        L.check(lib.ffn_pack_nchw(_stream(), _dt(out), CT.byref(d)), "ffn_pack_nchw")
     return out
 
 

@@ -22,9 +22,10 @@ ap.add_argument("--model", default="sd21-base")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--out", default="gpurun_out/shape_profile.txt")
 ap.add_argument("--no-dedup", action="store_true")
+ap.add_argument("--batch", type=int, default=1)
 a = ap.parse_args()
 
-args = argparse.Namespace(model=a.model, vae="sd", dtype=a.dtype, no_graph=True, no_dedup=a.no_dedup, num_step=a.num_step, start_step=0)
+args = argparse.Namespace(model=a.model, vae="sd", dtype=a.dtype, no_graph=True, no_dedup=a.no_dedup, num_step=a.num_step, start_step=0, batch=a.batch)
 dev = torch.device("cuda:0")
 model = bench.build_model(args, dev, 0, 1)
 bench.edit_once(model, args, 0)
@@ -138,7 +139,7 @@ rows.sort(key=lambda r: -r[0])
 tot = sum(r[0] for r in rows)
 os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
 with open(a.out, "w") as f:
-    hdr = f"# one {a.model} {a.dtype} edit, n={a.num_step}, dedup={not a.no_dedup}: {sum(r[1] for r in rows)} launches, modelled kernel time {tot / 1e3:.1f} ms\n"
+    hdr = f"# one {a.model} {a.dtype} edit x batch {a.batch}, n={a.num_step}, dedup={not a.no_dedup}: {sum(r[1] for r in rows)} launches, modelled kernel time {tot / 1e3:.1f} ms\n"
     f.write(hdr)
     f.write("total_ms\tshare\tcalls\tus_per_launch\tTFLOP/s\tkernel\tshape_key\n")
     for t, cnt, us, fl, name, k in rows:
