@@ -35,6 +35,25 @@ enum { ATT_HEAD_RULE = FFN_ATT_HEAD_RULE, ATT_UNIFORM_SEL1 = FFN_ATT_UNIFORM_SEL
 typedef ffn_attn_entry AttnEntry;
 typedef ffn_attn_desc AttnParams;
 
+// plain v_max3 / v_max (fmaxf on MFMA outputs makes the compiler insert a canonicalising v_max per operand)
+__device__ __forceinline__ float att_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float att_max(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// max over the four lanes l, l^16, l^32, l^48 (the four key groups of one query) without an LDS round trip
+__device__ __forceinline__ float att_max_groups(float x) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = att_max(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return att_max(__uint_as_float(c[0]), __uint_as_float(c[1]));
+}
+
 template <typename T, int DP, int QF, int KT = 64, int OCC = 1>   // KT = keys per tile, OCC = min waves per SIMD
 __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
     constexpr int EPC = DT<T>::EPC;
@@ -66,7 +85,14 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
     const T* __restrict__ Qg = reinterpret_cast<const T*>(p.q);
     const T* __restrict__ Kg = reinterpret_cast<const T*>(p.k);
     const T* __restrict__ Vg = reinterpret_cast<const T*>(p.vt);
-    const float c_exp = p.scale * 1.44269504088896340736f;   // softmax in base 2: p = exp2(s*c - m)
+    // bf16 fast path (FAST): Q is pre-multiplied by scale*log2(e) when its fragments are loaded, so the MFMA result already is the
+    // base-2 logit; full unmasked key tiles then start the S^T accumulator at -m (running reference), which removes the per-element
+    // scale-and-subtract, take the row sums from one extra MFMA against a ones operand, and only re-reference m when a tile exceeds
+    // it by more than FAST_THR (deferred rescale: any reference works as long as O, l and P share it).
+    constexpr bool FAST = std::is_same<T, bf16>::value;
+    constexpr float FAST_THR = 6.0f;
+    const float c_pre = p.scale * 1.44269504088896340736f;
+    const float c_exp = FAST ? 1.0f : c_pre;                 // softmax in base 2: p = exp2(s*c - m)
 
     // multi-pass sums live in LDS between passes (touched once per pass), not in registers: [wave][FD][QF][lane] f32x4
     f32x4* totl = reinterpret_cast<f32x4*>(smem + 2 * (KBUF + VBUF)) + wave * (FD * QF * 64) + lane;
@@ -114,6 +140,13 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
                 qf[f][s] = u32x4{0, 0, 0, 0};
                 if (qok && d < D)
                     qf[f][s] = *reinterpret_cast<const u32x4*>(Qg + ((long)en.q_row * p.S + q) * p.ldq + head * D + d);
+                if (FAST) {
+                    float tmp[EPC];
+                    DT<T>::unpack(qf[f][s], tmp);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) tmp[e] *= c_pre;
+                    qf[f][s] = DT<T>::pack(tmp);
+                }
             }
             wq[f] = (en.wq && qok) ? en.wq[q] : 1.f;
             int md = 0;
@@ -127,11 +160,13 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
         }
 
         f32x4 o[FD][QF];
+        f32x4 lacc[QF];             // FAST: row sums of the fast tiles (ones-operand MFMA), replicated over the lane's 4 registers
         float mrun[QF], lrun[QF];   // running max (already multiplied by c_exp) and per-lane partial row sum
 #pragma unroll
         for (int f = 0; f < QF; ++f) {
             mrun[f] = NEG;
             lrun[f] = 0.f;
+            lacc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < FD; ++i) o[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -192,14 +227,43 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int f = 0; f < QF; ++f) st[t][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            u32x4 vpre[FAST ? NT / KPC : 1][FAST ? FD : 1];   // FAST: V^T fragments requested before the softmax (see tile_fast)
+            if constexpr (FAST) {
+                u32x4 ka[DSL][NT];
 #pragma unroll
-            for (int s = 0; s < DSL; ++s) {
+                for (int s = 0; s < DSL; ++s)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int krow = t * 16 + l15;
-                    const u32x4 ka = *reinterpret_cast<const u32x4*>(Kb + krow * KROW + ((KSWZ ? ((4 * s + g) ^ (krow & 7)) : (4 * s + g)) << 4));
+                    for (int t = 0; t < NT; ++t) {
+                        const int krow = t * 16 + l15;
+                        ka[s][t] = *reinterpret_cast<const u32x4*>(Kb + krow * KROW + ((KSWZ ? ((4 * s + g) ^ (krow & 7)) : (4 * s + g)) << 4));
+                    }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int f = 0; f < QF; ++f) DT<T>::mma(ka, qf[f][s], st[t][f]);
+                for (int s = 0; s < DSL; ++s)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int f = 0; f < QF; ++f) DT<T>::mma(ka[s][t], qf[f][s], st[t][f]);
+#pragma unroll
+                for (int c = 0; c < NT / KPC; ++c)
+#pragma unroll
+                    for (int i = 0; i < FD; ++i) {
+                        const char* vrow = Vb + (i * 16 + l15) * VROW;
+                        const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + (32 * c + 4 * g) * SZ);
+                        const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (32 * c + 16 + 4 * g) * SZ);
+                        vpre[c][i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < DSL; ++s) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int krow = t * 16 + l15;
+                        const u32x4 ka = *reinterpret_cast<const u32x4*>(Kb + krow * KROW + ((KSWZ ? ((4 * s + g) ^ (krow & 7)) : (4 * s + g)) << 4));
+#pragma unroll
+                        for (int f = 0; f < QF; ++f) DT<T>::mma(ka, qf[f][s], st[t][f]);
+                    }
                 }
             }
             // masked path: bit (4t+r) of `inr` = key in range, of `mk` = kmask byte != 0 (keys 16t+4g+r of this lane)
@@ -266,6 +330,7 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
                 if (__any(grew)) {   // lazy rescale: exact, skipped once the running max has settled
 #pragma unroll
                     for (int i = 0; i < FD; ++i) o[i][f] *= alpha;
+                    if (FAST) lacc[f] *= alpha;
                 }
 #pragma unroll
                 for (int c = 0; c < NT / KPC; ++c) {
@@ -281,7 +346,9 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
                 for (int i = 0; i < FD; ++i) {
                     u32x4 va;
                     const char* vrow = Vb + (i * 16 + l15) * VROW;
-                    if (KPC == 1) {
+                    if constexpr (FAST) {
+                        va = vpre[c][i];
+                    } else if (KPC == 1) {
                         va = *reinterpret_cast<const u32x4*>(vrow + (16 * c + 4 * g) * SZ);
                     } else {
                         const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + (32 * c + 4 * g) * SZ);
@@ -294,6 +361,91 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
             }
         };
 
+
+        // ---- FAST: one full, unmasked key tile (bf16) ---------------------------------------------------------------------
+        auto tile_fast = [&](int buf, bool first) {
+            const char* Kb = Ks + buf * KBUF;
+            const char* Vb = Vs + buf * VBUF;
+            f32x4 st[NT][QF];
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                const float nm = first ? 0.f : -mrun[f];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) st[t][f] = f32x4{nm, nm, nm, nm};
+            }
+            // all K fragments of the tile are requested before the first MFMA (the compiler otherwise emits read -> wait -> 2 MFMA
+            // chains and every LDS latency is exposed); the V^T fragments are requested before the softmax and land under it
+            u32x4 ka[DSL][NT];
+#pragma unroll
+            for (int s = 0; s < DSL; ++s)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int krow = t * 16 + l15;
+                    ka[s][t] = *reinterpret_cast<const u32x4*>(Kb + krow * KROW + ((KSWZ ? ((4 * s + g) ^ (krow & 7)) : (4 * s + g)) << 4));
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < DSL; ++s)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int f = 0; f < QF; ++f) DT<T>::mma(ka[s][t], qf[f][s], st[t][f]);
+            u32x4 va[NT / KPC][FD];
+#pragma unroll
+            for (int c = 0; c < NT / KPC; ++c)
+#pragma unroll
+                for (int i = 0; i < FD; ++i) {
+                    const char* vrow = Vb + (i * 16 + l15) * VROW;
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + (32 * c + 4 * g) * SZ);
+                    const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (32 * c + 16 + 4 * g) * SZ);
+                    va[c][i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 pb[NT / KPC][QF];
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                float tm = att_max3(st[0][f][0], st[0][f][1], st[0][f][2]);
+                tm = att_max(tm, st[0][f][3]);
+#pragma unroll
+                for (int t = 1; t < NT; ++t) {
+                    tm = att_max3(tm, st[t][f][0], st[t][f][1]);
+                    tm = att_max3(tm, st[t][f][2], st[t][f][3]);
+                }
+                tm = att_max_groups(tm);
+                const bool need = first || tm > FAST_THR;
+                if (__any(need)) {            // re-reference: rare after the first tiles
+                    const float delta = need ? tm : 0.f;
+                    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+                    mrun[f] = first ? delta : mrun[f] + delta;
+                    lrun[f] *= alpha;
+                    lacc[f] *= alpha;
+#pragma unroll
+                    for (int i = 0; i < FD; ++i) o[i][f] *= alpha;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) st[t][f][r] -= delta;
+                }
+#pragma unroll
+                for (int c = 0; c < NT / KPC; ++c) {
+                    float tmp[EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) tmp[e] = __builtin_amdgcn_exp2f(st[c * KPC + e / 4][f][e & 3]);
+                    pb[c][f] = DT<T>::pack(tmp);
+                }
+            }
+            const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#pragma unroll
+            for (int c = 0; c < NT / KPC; ++c) {
+#pragma unroll
+                for (int f = 0; f < QF; ++f) DT<T>::mma(ones, pb[c][f], lacc[f]);
+#pragma unroll
+                for (int i = 0; i < FD; ++i)
+#pragma unroll
+                    for (int f = 0; f < QF; ++f) DT<T>::mma(va[c][i], pb[c][f], o[i][f]);
+            }
+        };
+
         issue(0);
         stage(0);
         __syncthreads();
@@ -302,6 +454,8 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
             if (t + 1 < ntiles) issue(k0 + KT);
             if (pass_masked || k0 + KT > p.Sk)
                 tile(k0, buf, std::true_type{});
+            else if constexpr (FAST)
+                tile_fast(buf, t == 0);
             else
                 tile(k0, buf, std::false_type{});
             if (t + 1 < ntiles) stage(buf ^ 1);
@@ -315,6 +469,7 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
             float l = lrun[f];
             l += __shfl_xor(l, 16);
             l += __shfl_xor(l, 32);
+            if (FAST) l += lacc[f][0];
             const float sc = (l > 0.f) ? (w * wq[f] / l) : 0.f;
             const int q = q0 + f * 16 + l15;
 #pragma unroll
