@@ -2,11 +2,14 @@
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
-One "step" = ONE edited image = one full `FreeFine_generation` call at 512x512 on SD-2.1-base topology (865.9 M parameter
-UNet + SD VAE, seeded synthetic weights: no checkpoints exist offline), N=50 DDIM schedule run in full (start_step=0:
-50 inversion forwards at UNet batch 2 + 50 guided-denoising forwards at UNet batch 4 with TCA attention injection in blocks
-10-15, local cross-attention, masked CFG, masked DDPM step) + VAE encode/decode, inputs resident on the GPU box's host
-(images are 768 KB; the PCIe upload is inside the timed region, as it is for the reference).
+One "step" = one pass of the hot path over one batch of synthetic inputs = `--concurrent` x `--batch` full `FreeFine_generation`
+edits at 512x512 on SD-2.1-base topology (865.9 M parameter UNet + SD VAE, seeded synthetic weights: no checkpoints exist
+offline), N=50 DDIM schedule run in full per image (start_step=0: 50 inversion forwards with 2 UNet rows per image + 50
+guided-denoising forwards with 4 logical UNet rows per image, TCA attention injection in blocks 10-15, local cross-attention,
+masked CFG, masked DDPM step) + VAE encode/decode.  `--batch K` independent edits (own images, masks, seeds) share one
+image-major UNet batch (FreeFine_generation_batch); `--concurrent C` such batches run on C HIP streams over the
+same weights.  value = images / second.  Inputs are host uint8 images (768 KB each; the PCIe upload is inside the timed region,
+as it is for the reference).
 Rank r edits its own images (weak scaling: independent units, no data-path collective); value = images of
 all ranks / max-over-ranks time.
 
@@ -113,9 +116,20 @@ def roofline_leg(model, args):
     peak = PEAK_TFLOPS[args.dtype]
     total_ms = sum(v["total_ms"] for v in prof.values())
     table = sorted(((k, v["calls"], v["total_ms"], v["flops"] / max(v["total_ms"], 1e-9) / 1e9) for k, v in prof.items()), key=lambda t: -t[2])
-    return dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
-                traffic=None, launches=d["calls"], avg_launch_us=round(avg_ms * 1e3, 2),
-                share_of_timed_kernels=round(d["total_ms"] / total_ms, 3)), table
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/pmc.sh; FETCH_SIZE x2 per the gfx950
+    # correction of MI355X_MICROARCH.md, WRITE_SIZE), recorded per round under profiles/: reported only if it is the same kernel
+    traffic, traffic_note = None, None
+    pmc = os.path.join(ROOT, "profiles", "r1_pmc_dominant.json")
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc))
+        if rec.get("kernel") == name:
+            traffic, traffic_note = rec["traffic_bytes_per_launch"], rec.get("note")
+    out = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
+               traffic=traffic, launches=d["calls"], avg_launch_us=round(avg_ms * 1e3, 2),
+               share_of_timed_kernels=round(d["total_ms"] / total_ms, 3))
+    if traffic_note:
+        out["traffic_note"] = traffic_note
+    return out, table
 
 
 def cpu_baseline_leg(args):
@@ -237,8 +251,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"SD-2.1-base topology ({args.model}) 512x512 FreeFine_generation edit, {args.num_step}-step DDIM schedule "
-                                   f"(start_step={args.start_step}: {n} inversion forwards B=2 + {n} guided forwards B=4, TCA blocks 10-15, "
-                                   "masked CFG 7.5, eta=1) + VAE bracket; seeded random weights",
+                                   f"(start_step={args.start_step}: per image {n} inversion forwards x 2 rows + {n} guided forwards x 4 rows, TCA blocks "
+                                   f"10-15, masked CFG 7.5, eta=1) + VAE bracket; {args.batch} independent edits per UNet batch x "
+                                   f"{args.concurrent} HIP streams; seeded random weights",
                        "images_per_gpu_per_step": args.concurrent * args.batch, "concurrent_streams": args.concurrent,
                        "images_per_unet_batch": args.batch, "unet_batch": 4 * args.batch, "hip_graph": not args.no_graph,
                        "exact_row_dedup": model.dedup_rows and "on: the duplicated reference row of the CFG batch is evaluated once (3 physical rows), outputs unchanged",

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfreefine_hip.so")
+LIB_PATH = os.environ.get("FREEFINE_HIP_LIB") or os.path.join(_HERE, "libfreefine_hip.so")   # env override: A/B builds of the same ABI
 
 FFN_F32, FFN_BF16 = 0, 1
 IG_OUT_SILU, IG_OUT_F32, IG_GEGLU, IG_OUT_TRANSPOSED = 1, 2, 4, 8

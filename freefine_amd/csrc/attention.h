@@ -29,6 +29,9 @@
 #include "common.h"
 #include "../../include/freefine_hip.h"
 
+#ifndef ATT_XCD_MIN_GROUPS
+#define ATT_XCD_MIN_GROUPS 64
+#endif
 #define ATT_MAXP FFN_ATT_MAXP
 #define ATT_MAXB FFN_ATT_MAXB
 enum { ATT_HEAD_RULE = FFN_ATT_HEAD_RULE, ATT_UNIFORM_SEL1 = FFN_ATT_UNIFORM_SEL1, ATT_UNIFORM_SEL0 = FFN_ATT_UNIFORM_SEL0 };
@@ -79,8 +82,12 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, head = blockIdx.y;
-    const int q0 = blockIdx.x * (64 * QF) + wave * (16 * QF);
+    const int nqb = (p.S + 64 * QF - 1) / (64 * QF);
+    // XCD-contiguous logical order (query block fastest, then head, then row) once every XCD gets many (row, head) groups; with
+    // few groups (single-image batches) whole groups of unequal cost (masked / unmasked heads) per XCD unbalance the chip instead
+    const int Lb = (p.heads * p.Bo >= ATT_XCD_MIN_GROUPS) ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int qblk = Lb % nqb, head = (Lb / nqb) % p.heads, b = Lb / (nqb * p.heads);
+    const int q0 = qblk * (64 * QF) + wave * (16 * QF);
     const int D = p.D;
     const T* __restrict__ Qg = reinterpret_cast<const T*>(p.q);
     const T* __restrict__ Kg = reinterpret_cast<const T*>(p.k);

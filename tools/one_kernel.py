@@ -12,7 +12,7 @@ dt = torch.bfloat16
 g = torch.Generator().manual_seed(0)
 rnd = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(dt).to(dev)
 kind = sys.argv[1]
-B = 4
+B = int(os.environ.get("ONE_B", 4))
 if kind == "conv":
     hw, cin, cout = map(int, sys.argv[2:5])
     x = rnd(B, hw * hw, cin)
