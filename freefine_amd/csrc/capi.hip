@@ -83,11 +83,34 @@ static int igemm_stages_env() {
     }();
     return v;
 }
+static int device_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+static bool persist_enabled() {
+    static const bool on = [] { const char* e = getenv("FFN_IGEMM_PERSIST"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+// persist: the 2-stage glds kernels walk several output tiles per workgroup (igemm.h); launch only as many workgroups as are
+// co-resident (LDS / thread limits per CU) and let each stride over the tile list
 template <typename K>
-static int launch_igemm_kernel(K kern, int lds, hipStream_t s, const ffn_igemm_desc& d, int ntiles, int splitk, int threads = 256) {
+static int launch_igemm_kernel(K kern, int lds, hipStream_t s, const ffn_igemm_desc& d, int ntiles, int splitk, int threads = 256,
+                               bool persist = false) {
     int rc = set_lds(kern, lds);
     if (rc) return rc;
-    LAUNCH(kern, dim3(ntiles, splitk), dim3(threads), lds, s, d);
+    int gx = ntiles;
+    if (persist && persist_enabled()) {
+        int per_cu = (160 * 1024) / (lds > 0 ? lds : 1);
+        if (per_cu > 2048 / threads) per_cu = 2048 / threads;
+        if (per_cu < 1) per_cu = 1;
+        const int cap = (device_cus() * per_cu) / (splitk > 0 ? splitk : 1);
+        if (gx > cap && cap >= 8) gx = cap;
+    }
+    LAUNCH(kern, dim3(gx, splitk), dim3(threads), lds, s, d);
     return check_launch("igemm");
 }
 static int igemm_waves_env() {
@@ -229,17 +252,25 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
     const int ntiles = ((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn);
     const int lds = 2 * (c.bm + c.bn) * 128, threads = 64 * c.nwm * c.nwn;
     int rc = FFN_OK;
+    // FASTK kernels (streaming loader) need every 128-byte K stage inside K / inside one conv tap
+    const bool fastk = d.conv ? (d.Cin % 64 == 0 && d.Cin <= 30000) : (d.K % 64 == 0 && d.K <= 30000);   // 64 KiB zero page
+#define FFN_CFG_CASE(ID, BM_, BN_, WM_, WN_)                                                                                               \
+    case ID:                                                                                                                        \
+        rc = fastk ? launch_igemm_kernel(igemm_glds_kernel<bf16, BM_, BN_, AMODE, true, 2, WM_, WN_, true>, lds, s, d, ntiles, ch.splitk, threads, true)  \
+                   : launch_igemm_kernel(igemm_glds_kernel<bf16, BM_, BN_, AMODE, true, 2, WM_, WN_, false>, lds, s, d, ntiles, ch.splitk, threads, true); \
+        break;
     switch (ch.cfg) {
-        case CFG_64x64: rc = launch_igemm_kernel(igemm_glds_kernel<bf16, 64, 64, AMODE, true, 2, 2, 2>, lds, s, d, ntiles, ch.splitk, threads); break;
-        case CFG_128x64: rc = launch_igemm_kernel(igemm_glds_kernel<bf16, 128, 64, AMODE, true, 2, 4, 2>, lds, s, d, ntiles, ch.splitk, threads); break;
-        case CFG_128x128_8: rc = launch_igemm_kernel(igemm_glds_kernel<bf16, 128, 128, AMODE, true, 2, 2, 4>, lds, s, d, ntiles, ch.splitk, threads); break;
-        case CFG_128x128_16: rc = launch_igemm_kernel(igemm_glds_kernel<bf16, 128, 128, AMODE, true, 2, 4, 4>, lds, s, d, ntiles, ch.splitk, threads); break;
-        case CFG_256x128: rc = launch_igemm_kernel(igemm_glds_kernel<bf16, 256, 128, AMODE, true, 2, 4, 4>, lds, s, d, ntiles, ch.splitk, threads); break;
-        case CFG_256x256: rc = launch_igemm_kernel(igemm_glds_kernel<bf16, 256, 256, AMODE, true, 2, 4, 4>, lds, s, d, ntiles, ch.splitk, threads); break;
-        case CFG_128x320: rc = launch_igemm_kernel(igemm_glds_kernel<bf16, 128, 320, AMODE, true, 2, 4, 4>, lds, s, d, ntiles, ch.splitk, threads); break;
-        case CFG_128x160: rc = launch_igemm_kernel(igemm_glds_kernel<bf16, 128, 160, AMODE, true, 2, 4, 2>, lds, s, d, ntiles, ch.splitk, threads); break;
+        FFN_CFG_CASE(CFG_64x64, 64, 64, 2, 2)
+        FFN_CFG_CASE(CFG_128x64, 128, 64, 4, 2)
+        FFN_CFG_CASE(CFG_128x128_8, 128, 128, 2, 4)
+        FFN_CFG_CASE(CFG_128x128_16, 128, 128, 4, 4)
+        FFN_CFG_CASE(CFG_256x128, 256, 128, 4, 4)
+        FFN_CFG_CASE(CFG_256x256, 256, 256, 4, 4)
+        FFN_CFG_CASE(CFG_128x320, 128, 320, 4, 4)
+        FFN_CFG_CASE(CFG_128x160, 128, 160, 4, 2)
         default: return fail(FFN_EINVAL, "igemm: bad configuration %d", ch.cfg);
     }
+#undef FFN_CFG_CASE
     if (rc || ch.splitk == 1) return rc;
     const long nq = (long)d.M * (d.N / 4);
     LAUNCH(igemm_splitk_reduce_kernel<bf16>, dim3(grid_for(nq)), dim3(256), 0, s, d, ch.splitk);
@@ -290,7 +321,7 @@ static int candidates_for(const ffn_igemm_desc& d, IgChoice* out, int cap) {
     const long per = (long)d.M * d.N * 4;
     for (int cfg = 0; cfg < CFG_COUNT; ++cfg) {
         const IgCfgInfo& c = kCfg[cfg];
-        if ((cfg == CFG_128x320 || cfg == CFG_128x160) && (d.flags & FFN_IG_GEGLU)) continue;              // odd number of column blocks per wave
+        if ((cfg == CFG_128x320 || cfg == CFG_128x160) && (d.flags & FFN_IG_GEGLU)) continue;   // odd number of column blocks per wave
         if (c.bm > 64 && c.bm >= 2 * d.M) continue;                                // tile mostly empty
         if (c.bn > 64 && c.bn >= 2 * d.N) continue;
         if (cfg == CFG_64x64 && (long)d.M * d.N > (1l << 22)) continue;
@@ -315,8 +346,22 @@ static int candidates_for(const ffn_igemm_desc& d, IgChoice* out, int cap) {
     }
     return n;
 }
+static int g_force_cfg = -1;     // testing hook (ffn_igemm_force_config): run every bf16 problem on this configuration where it is valid
+extern "C" int ffn_igemm_num_configs(void) { return CFG_COUNT; }
+extern "C" int ffn_igemm_force_config(int cfg) {
+    const int prev = g_force_cfg;
+    g_force_cfg = (cfg >= 0 && cfg < CFG_COUNT) ? cfg : -1;
+    return prev;
+}
 template <int AMODE>
 static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
+    if (g_force_cfg >= 0) {
+        IgChoice cand[24];
+        const int nc = candidates_for(d, cand, 24);
+        for (int i = 0; i < nc; ++i)
+            if (cand[i].cfg == g_force_cfg) return launch_bf16_cfg<AMODE>(s, d, cand[i]);
+        return launch_bf16_cfg<AMODE>(s, d, heuristic_choice(d));     // not valid for this problem
+    }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
     const bool aliased = d.residual == d.out;        // repeated launches would accumulate: never time such a call
@@ -370,7 +415,9 @@ extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d, char* b
     if (dtype == FFN_BF16 && !(d->flags & FFN_IG_OUT_TRANSPOSED)) {      // the tuned (or, untuned, rule-based) bf16 configuration
         if (!tuned_lookup(*d, &ch)) ch = heuristic_choice(*d);
         const IgCfgInfo& c = kCfg[ch.cfg];
-        snprintf(buf, len, "void igemm_glds_kernel<bf16, %d, %d, %d, true, 2, %d, %d>(ffn_igemm_desc)", c.bm, c.bn, d->conv ? 1 : 0, c.nwm, c.nwn);
+        const bool fastk = d->conv ? (d->Cin % 64 == 0 && d->Cin <= 30000) : (d->K % 64 == 0 && d->K <= 30000);
+        snprintf(buf, len, "void igemm_glds_kernel<bf16, %d, %d, %d, true, 2, %d, %d, %s>(ffn_igemm_desc)", c.bm, c.bn, d->conv ? 1 : 0, c.nwm, c.nwn,
+                 fastk ? "true" : "false");
         return FFN_OK;
     }
     igemm_plan_for(dtype, *d, &bm, &bn, &sk);
@@ -380,7 +427,7 @@ extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d, char* b
     if (ns == 1) snprintf(buf, len, "void igemm_kernel<%s, %d, %d, %d, %s>(ffn_igemm_desc)", t, bm, bn, d->conv ? 1 : 0, swap);
     else {
         const int nwm = nw == 16 ? 4 : (nw == 8 ? (bn == 64 ? 4 : 2) : 2), nwn = nw / nwm;
-        snprintf(buf, len, "void igemm_glds_kernel<%s, %d, %d, %d, %s, %d, %d, %d>(ffn_igemm_desc)", t, bm, bn, d->conv ? 1 : 0, swap, ns, nwm, nwn);
+        snprintf(buf, len, "void igemm_glds_kernel<%s, %d, %d, %d, %s, %d, %d, %d, false>(ffn_igemm_desc)", t, bm, bn, d->conv ? 1 : 0, swap, ns, nwm, nwn);
     }
     return FFN_OK;
 }

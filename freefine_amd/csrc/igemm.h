@@ -307,12 +307,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 // (conv zero padding, M/N/K tails) are fetched from a 16-byte zero page.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) const uint32_t g_zero_chunk[4] = {0, 0, 0, 0};
+// the streaming loader's out-of-range pointers walk forward 128 B per stage like the real ones: a zero PAGE long enough for one
+// conv tap / one dense K row (64 KiB covers 32768 bf16 or 16384 f32 elements), so no per-piece stride register is needed
+__device__ __attribute__((aligned(128))) const uint32_t g_zero_page[16384] = {0};
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // NS = LDS ring depth (NS-1 stages in flight), NWM x NWN = wave grid over the BM x BN tile (4 or 8 waves)
-template <typename T, int BM, int BN, int AMODE, bool SWAP, int NS = 2, int NWM = 2, int NWN = 2>
+// FASTK: the caller guarantees K % 64-byte-stage == 0 (dense) / Cin % stage == 0 (conv): the streaming loader below is used
+template <typename T, int BM, int BN, int AMODE, bool SWAP, int NS = 2, int NWM = 2, int NWN = 2, bool FASTK = false>
 __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmParams p) {
     constexpr int EPC = DT<T>::EPC;
     constexpr int BKE = 8 * EPC;  // K elements per stage (128 bytes)
@@ -334,10 +338,17 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
     const int wm = wave / NWN, wn = wave % NWN;
     const int l15 = lane & 15, g = lane >> 4;
 
+    // PERSISTENT over output tiles: block b handles logical tiles xcd_remap(b, G) + j*G, j = 0, 1, ... (G = gridDim.x): at every
+    // step j the G resident blocks cover a contiguous run of logical tiles, XCD-contiguous inside it (neighbours share operand
+    // panels in that XCD's L2).  The stage ring runs straight across tile boundaries: the first stage of the NEXT tile is
+    // requested before the last stage of the current one is multiplied, so the epilogue's stores and the next tile's first load
+    // overlap (measured: 0-7% on the K = 320 / 640 Linear layers, neutral on the long-K convolutions).
     const int ntn = (p.N + BN - 1) / BN;
     const int ntm = (p.M + BM - 1) / BM;
-    const int L = xcd_remap(blockIdx.x, ntm * ntn);
-    const int m0 = (L / ntn) * BM, n0 = (L % ntn) * BN;
+    const int ntiles = ntm * ntn;
+    const int G = gridDim.x;
+    int tile = xcd_remap(blockIdx.x, G);
+    int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
 
     const int lrow = lane >> 3;             // row inside this wave-instruction's 8-row group
     const int csrc = (lane & 7) ^ lrow;     // global chunk this lane fetches (source-side swizzle)
@@ -348,30 +359,33 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
     long a_base[NA];
     int a_y[NA], a_x[NA];
     bool a_ok[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int m = m0 + 8 * (wave + NW * i) + lrow;
-        a_ok[i] = m < p.M;
-        if (AMODE == AMODE_DENSE) {
-            a_base[i] = (long)m * p.lda;
-            a_y[i] = a_x[i] = 0;
-        } else {
-            const int hw = p.Hout * p.Wout;
-            const int b = m / hw, rem = m - b * hw;
-            const int yo = rem / p.Wout, xo = rem - yo * p.Wout;
-            a_base[i] = (long)b * p.Hin * p.Win;
-            a_y[i] = yo * p.stride - p.pad;
-            a_x[i] = xo * p.stride - p.pad;
-        }
-    }
     long b_base[NB];
     bool b_ok[NB];
+    auto prep = [&](int mt, int nt) {       // loader state of the tile whose stages are requested next
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int n = n0 + 8 * (wave + NW * i) + lrow;
-        b_ok[i] = n < p.N;
-        b_base[i] = (long)n * p.Kpad;
-    }
+        for (int i = 0; i < NA; ++i) {
+            const int m = mt + 8 * (wave + NW * i) + lrow;
+            a_ok[i] = m < p.M;
+            if (AMODE == AMODE_DENSE) {
+                a_base[i] = (long)m * p.lda;
+                a_y[i] = a_x[i] = 0;
+            } else {
+                const int hw = p.Hout * p.Wout;
+                const int b = m / hw, rem = m - b * hw;
+                const int yo = rem / p.Wout, xo = rem - yo * p.Wout;
+                a_base[i] = (long)b * p.Hin * p.Win;
+                a_y[i] = yo * p.stride - p.pad;
+                a_x[i] = xo * p.stride - p.pad;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int n = nt + 8 * (wave + NW * i) + lrow;
+            b_ok[i] = n < p.N;
+            b_base[i] = (long)n * p.Kpad;
+        }
+    };
+    prep(m0, n0);
     const int He = p.Hin << p.upsample, We = p.Win << p.upsample;
 
     auto issue = [&](int kt, int buf) {
@@ -403,6 +417,63 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
             if (GB % NW != 0 && wave + NW * i >= GB) continue;
             const char* src = (b_ok[i] && kin) ? reinterpret_cast<const char*>(Wg + b_base[i] + kk) : zero;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + buf * BN * 128 + (8 * (wave + NW * i)) * 128), 16, 0, 0);
+        }
+    };
+
+    // ---- streaming loader (FASTK: every 128-byte K stage lies inside one conv tap / inside K): per wave-instruction the lane keeps
+    // a running source pointer and a stride (128 B, or 0 while it reads the zero page), so a stage costs one 64-bit add per piece
+    // instead of an integer division, the pixel / bounds arithmetic and two selects (the ISA of the recomputing loader showed ~120
+    // scalar+vector instructions per stage per wave beside 20 MFMAs: the convolutions were ISSUE bound, 39% MFMA busy).
+    constexpr bool fastk = FASTK && NS == 2;
+    const char* a_cur[NA];
+    const char* b_cur[NB];
+    const char* zpage = reinterpret_cast<const char*>(g_zero_page) + csrc * 16;
+    int tap_cur = 0, ci_cur = 0;                     // conv: tap of the stage the pointers stand on, channel offset inside it
+    auto set_tap = [&](int tap, int ci) {            // conv: pointers of every A row for (tap, channel offset ci)
+        const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            int yy = a_y[i] + ky, xx = a_x[i] + kx;   // rows past M carry a_y = INT_MIN/2: they fail the bounds test
+            const bool inb = (unsigned)yy < (unsigned)He && (unsigned)xx < (unsigned)We;
+            yy >>= p.upsample;
+            xx >>= p.upsample;
+            const long pix = a_base[i] + (long)yy * p.Win + xx;
+            a_cur[i] = inb ? reinterpret_cast<const char*>(Ag + pix * p.Cin + ci + csrc * EPC) : zpage;
+        }
+        tap_cur = tap;
+        ci_cur = ci;
+    };
+    auto seek = [&](int kt) {                        // pointers of the tile prepared by prep() at K stage kt
+        const int kk = kt * BKE;
+        if (AMODE == AMODE_DENSE) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) a_cur[i] = a_ok[i] ? reinterpret_cast<const char*>(Ag + a_base[i] + kk + csrc * EPC) : zpage;
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                if (!a_ok[i]) a_y[i] = -(1 << 30);
+            const int tap = kk / p.Cin;
+            set_tap(tap, kk - tap * p.Cin);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) b_cur[i] = b_ok[i] ? reinterpret_cast<const char*>(Wg + b_base[i] + kk + csrc * EPC) : zpage;
+    };
+    auto issue_next = [&](int buf) {                 // request the stage the pointers stand on, then advance them by one stage
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (GA % NW != 0 && wave + NW * i >= GA) continue;
+            __builtin_amdgcn_global_load_lds((gptr_t)a_cur[i], (lptr_t)(As + buf * BM * 128 + (8 * (wave + NW * i)) * 128), 16, 0, 0);
+            a_cur[i] += 128;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (GB % NW != 0 && wave + NW * i >= GB) continue;
+            __builtin_amdgcn_global_load_lds((gptr_t)b_cur[i], (lptr_t)(Bs + buf * BN * 128 + (8 * (wave + NW * i)) * 128), 16, 0, 0);
+            b_cur[i] += 128;
+        }
+        if (AMODE != AMODE_DENSE) {
+            ci_cur += BKE;
+            if (ci_cur >= p.Cin) set_tap(tap_cur + 1, 0);      // wave-uniform: every Cin/64 stages
         }
     };
 
@@ -448,21 +519,63 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
     // ring of NS LDS stages, NS-1 of them in flight; every issue() is exactly NLD wave-instructions, so "stage kt has landed"
     // is a COUNTED wait (vmcnt = NLD x stages issued after it), the DMA of later stages stays in flight across the barrier
     constexpr int NLD = NA + NB;
+    if constexpr (NS == 2) {
+        if (kt0 < nk) {
+            if constexpr (fastk) {
+                seek(kt0);
+                issue_next(0);
+            } else {
+                issue(kt0, 0);
+            }
+        }
+        int buf = 0;
+        while (true) {
+            const int next = tile + G;
+            for (int kt = kt0; kt < nk; ++kt) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();   // stage kt visible to all waves; all waves are done with the previous stage -> its buffer is free
+                if (kt + 1 < nk) {
+                    if constexpr (fastk) issue_next(buf ^ 1);
+                    else issue(kt + 1, buf ^ 1);
+                } else if (next < ntiles) {     // last stage of this tile: request the next tile's first stage before multiplying
+                    prep((next / ntn) * BM, (next % ntn) * BN);
+                    if constexpr (fastk) {
+                        seek(kt0);
+                        issue_next(buf ^ 1);
+                    } else {
+                        issue(kt0, buf ^ 1);
+                    }
+                }
+                compute(buf);
+                buf ^= 1;
+            }
+            igemm_epilogue<T, FM, FN, SWAP>(p, acc, m0 + wm * WM, n0 + wn * WN, l15, g);
+            if (next >= ntiles) break;
+            tile = next;
+            m0 = (tile / ntn) * BM;
+            n0 = (tile % ntn) * BN;
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (kt0 + s < nk) issue(kt0 + s, s);
-    int buf = 0;
-    for (int kt = kt0; kt < nk; ++kt) {
-        const int ahead = min(NS - 2, nk - 1 - kt);     // stages issued after stage kt
-        if (NS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
-        else if (NS >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // stage kt visible to all waves; all waves are done with stage kt-1 -> its buffer is free
-        if (kt + NS - 1 < nk) issue(kt + NS - 1, (buf + NS - 1) % NS);
-        compute(buf);
-        buf = (buf + 1 == NS) ? 0 : buf + 1;
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    } else {                                    // deeper rings: one tile per block (launched with gridDim.x == number of tiles)
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (kt0 + s < nk) issue(kt0 + s, s);
+        int buf = 0;
+        for (int kt = kt0; kt < nk; ++kt) {
+            const int ahead = min(NS - 2, nk - 1 - kt);     // stages issued after stage kt
+            if (NS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+            else if (NS >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + NS - 1 < nk) issue(kt + NS - 1, (buf + NS - 1) % NS);
+            compute(buf);
+            buf = (buf + 1 == NS) ? 0 : buf + 1;
+        }
+        igemm_epilogue<T, FM, FN, SWAP>(p, acc, m0 + wm * WM, n0 + wn * WN, l15, g);
     }
-    igemm_epilogue<T, FM, FN, SWAP>(p, acc, m0 + wm * WM, n0 + wn * WN, l15, g);
 }
 
 // split-K finish: out[m, n..n+3] = epilogue(sum_s slab[s][m][n..n+3])  (same epilogue as the SWAP path of igemm_kernel)

@@ -62,6 +62,12 @@ typedef struct ffn_igemm_desc {
     long ws_bytes;
 } ffn_igemm_desc;
 int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
+/* bf16 problems: the first time a problem shape is seen outside stream capture, ffn_igemm times its few plausible (tile, K-split)
+ * configurations on the caller's stream (this one call synchronises the stream and launches the kernel several times: `out` must
+ * not alias `residual`) and caches the winner; FFN_IGEMM_TUNE=0 in the environment keeps the deterministic rule-based choice
+ * (f32 always uses it).  Testing hooks: the number of bf16 configurations, and forcing one (-1 = off; returns the previous value). */
+int ffn_igemm_num_configs(void);
+int ffn_igemm_force_config(int cfg);
 /* which tile (BM x BN) ffn_igemm dispatches for this problem -- lets a profiler name the kernel instantiation */
 int ffn_igemm_variant(const ffn_igemm_desc* d, int* bm, int* bn);
 /* the kernel instantiation ffn_igemm launches for this problem, spelled like rocprofv3's kernel trace */

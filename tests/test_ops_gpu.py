@@ -387,3 +387,42 @@ def test_splitk_conv_and_linear(gpu, dtype, splitk):
     assert relerr(out, F.silu(a.double() @ wl.double().t())) < tol(dtype)
     out = ops.linear(a, ops.pack_linear(wl, dtype), None, out_f32=True, splitk=splitk)
     assert out.dtype == torch.float32 and relerr(out, a.double() @ wl.double().t()) < tol(dtype)
+
+
+def test_every_bf16_igemm_configuration(gpu):
+    """ffn_igemm picks (tile, K-split) per shape by timing; force EVERY bf16 configuration in turn (incl. the 256x256 / 128x320
+    tiles, the persistent tile walk and the weight-stationary kernels) on shapes where it is valid and check the result."""
+    from freefine_amd import _lib as L
+    from freefine_amd import ops
+    lib = L.load()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    try:
+        for cfg in range(lib.ffn_igemm_num_configs()):
+            lib.ffn_igemm_force_config(cfg)
+            # dense, K = 320 (weight panel fits the LDS), bias + residual; ragged M / N
+            for (M, N, K) in [(16384 + 72, 320, 320), (20000, 640, 640), (300, 328, 136)]:
+                x, w = rnd((M, K), dt, gpu, g), rnd((N, K), dt, gpu, g, K ** -0.5)
+                b, r = rnd((N,), torch.float32, gpu, g), rnd((M, N), dt, gpu, g)
+                out = ops.linear(x, ops.pack_linear(w, dt), b, K=K, residual=r)
+                ref = x.double().cpu() @ w.double().cpu().t() + b.double().cpu() + r.double().cpu()
+                assert relerr(out, ref) < tol(dt), (cfg, M, N, K)
+            # GEGLU epilogue
+            M, K, F = 16384, 320, 640
+            x, w, b = rnd((M, K), dt, gpu, g), rnd((2 * F, K), dt, gpu, g, K ** -0.5), rnd((2 * F,), torch.float32, gpu, g)
+            wp, bp = ops.pack_geglu(w, b, dt)
+            out = ops.linear(x, wp, bp, K=K, geglu=True)
+            y = x.double().cpu() @ w.double().cpu().t() + b.double().cpu()
+            ref = y[:, :F] * torch.nn.functional.gelu(y[:, F:])
+            assert relerr(out, ref) < tol(dt), (cfg, "geglu")
+            # 3x3 conv with time-embedding row bias and residual
+            B, H, Cin, Cout = 3, 24, 64, 320
+            x, w = rnd((B, H * H, Cin), dt, gpu, g), rnd((Cout, Cin, 3, 3), dt, gpu, g, (9 * Cin) ** -0.5)
+            b, rb, r = rnd((Cout,), torch.float32, gpu, g), rnd((B, Cout), torch.float32, gpu, g), rnd((B, H * H, Cout), dt, gpu, g)
+            out = ops.conv3x3(x, ops.pack_conv3x3(w, dt), b, B, H, H, Cin, rowbias=rb, residual=r)
+            xr = x.double().cpu().reshape(B, H, H, Cin).permute(0, 3, 1, 2)
+            ref = torch.nn.functional.conv2d(xr, w.double().cpu(), b.double().cpu(), padding=1) + rb.double().cpu()[:, :, None, None]
+            ref = ref.permute(0, 2, 3, 1).reshape(B, H * H, Cout) + r.double().cpu()
+            assert relerr(out, ref) < tol(dt), (cfg, "conv")
+    finally:
+        lib.ffn_igemm_force_config(-1)
