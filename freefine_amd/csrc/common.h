@@ -114,6 +114,26 @@ __device__ __forceinline__ void load4(const bf16* p, float* v) {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_rcp, one v_exp and six FMAs instead of libm's branchy ~30-instruction
+// erff.  Used where the result is rounded to bf16 (2^-9) anyway: the GEGLU epilogue of the K = 320 feed-forward GEMM spent more
+// issue slots on erff than its five K stages spent on MFMAs.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    const float erf_abs = fmaf(-poly * t, e, 1.0f);          // erf(|x|/sqrt2)
+    const float cdf = 0.5f + copysignf(0.5f * erf_abs, x);
+    return x * cdf;
+}
+template <typename T>
+__device__ __forceinline__ float gelu_for(float x) {
+    if constexpr (sizeof(T) == 2) return gelu_erf_fast(x);
+    else return gelu_erf(x);
+}
 
 // Bijective XCD-aware remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch), so give
 // every XCD a contiguous run of logical tiles (neighbouring tiles share operand panels -> L2 hits).

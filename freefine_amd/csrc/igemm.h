@@ -70,7 +70,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
                                 h += p.bias[nh + r];
                                 gt += p.bias[nh + 16 + r];
                             }
-                            v[r] = h * gelu_erf(gt);
+                            v[r] = h * gelu_for<T>(gt);
                         }
                         const int no = (nbase) / 2 + (j / 2) * 16 + 4 * g;
                         store4(outT + (long)m * p.ldo + no, v);
