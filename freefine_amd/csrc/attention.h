@@ -35,6 +35,7 @@
 #define ATT_MAXP FFN_ATT_MAXP
 #define ATT_MAXB FFN_ATT_MAXB
 enum { ATT_HEAD_RULE = FFN_ATT_HEAD_RULE, ATT_UNIFORM_SEL1 = FFN_ATT_UNIFORM_SEL1, ATT_UNIFORM_SEL0 = FFN_ATT_UNIFORM_SEL0 };
+typedef __attribute__((address_space(3))) u32x2 lds_u32x2_t;   // explicit LDS pointer type for the volatile V^T fragment reads
 typedef ffn_attn_entry AttnEntry;
 typedef ffn_attn_desc AttnParams;
 
@@ -256,8 +257,8 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
 #pragma unroll
                     for (int i = 0; i < FD; ++i) {
                         const char* vrow = Vb + (i * 16 + l15) * VROW;
-                        const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + (32 * c + 4 * g) * SZ);
-                        const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (32 * c + 16 + 4 * g) * SZ);
+                        const u32x2 lo = *(const volatile lds_u32x2_t*)(vrow + (32 * c + 4 * g) * SZ);   // volatile: keep two ds_read_b64 (a merged ds_read2_b64 banks mod 32: 2-way conflicts, half rate)
+                        const u32x2 hi = *(const volatile lds_u32x2_t*)(vrow + (32 * c + 16 + 4 * g) * SZ);
                         vpre[c][i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
                     }
                 __builtin_amdgcn_sched_barrier(0);
@@ -358,8 +359,8 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
                     } else if (KPC == 1) {
                         va = *reinterpret_cast<const u32x4*>(vrow + (16 * c + 4 * g) * SZ);
                     } else {
-                        const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + (32 * c + 4 * g) * SZ);
-                        const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (32 * c + 16 + 4 * g) * SZ);
+                        const u32x2 lo = *(const volatile lds_u32x2_t*)(vrow + (32 * c + 4 * g) * SZ);   // volatile: keep two ds_read_b64 (a merged ds_read2_b64 banks mod 32: 2-way conflicts, half rate)
+                        const u32x2 hi = *(const volatile lds_u32x2_t*)(vrow + (32 * c + 16 + 4 * g) * SZ);
                         va = u32x4{lo[0], lo[1], hi[0], hi[1]};
                     }
 #pragma unroll
@@ -403,8 +404,8 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
 #pragma unroll
                 for (int i = 0; i < FD; ++i) {
                     const char* vrow = Vb + (i * 16 + l15) * VROW;
-                    const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + (32 * c + 4 * g) * SZ);
-                    const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (32 * c + 16 + 4 * g) * SZ);
+                    const u32x2 lo = *(const volatile lds_u32x2_t*)(vrow + (32 * c + 4 * g) * SZ);   // volatile: keep two ds_read_b64 (a merged ds_read2_b64 banks mod 32: 2-way conflicts, half rate)
+                    const u32x2 hi = *(const volatile lds_u32x2_t*)(vrow + (32 * c + 16 + 4 * g) * SZ);
                     va[c][i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
                 }
             __builtin_amdgcn_sched_barrier(0);
