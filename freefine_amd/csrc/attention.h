@@ -58,7 +58,9 @@ __device__ __forceinline__ float att_max_groups(float x) {
     return att_max(__uint_as_float(c[0]), __uint_as_float(c[1]));
 }
 
-template <typename T, int DP, int QF, int KT = 64, int OCC = 1>   // KT = keys per tile, OCC = min waves per SIMD
+// KT = keys per tile, OCC = min waves per SIMD, MASKS = some entry of the launch carries a key mask (bf16: compiles the
+// mask-on-MFMA tile in; launches without masks -- cross attention, plain self attention -- get the leaner kernel)
+template <typename T, int DP, int QF, int KT = 64, int OCC = 1, bool MASKS = true>
 __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
     constexpr int EPC = DT<T>::EPC;
     constexpr int SZ = sizeof(T);
@@ -98,12 +100,14 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
     // scale-and-subtract, take the row sums from one extra MFMA against a ones operand, and only re-reference m when a tile exceeds
     // it by more than FAST_THR (deferred rescale: any reference works as long as O, l and P share it).
     constexpr bool FAST = std::is_same<T, bf16>::value;
+    constexpr bool FAUG = FAST && MASKS;      // the mask k-step variant of the fast tile exists
     constexpr float FAST_THR = 6.0f;
     const float c_pre = p.scale * 1.44269504088896340736f;
     const float c_exp = FAST ? 1.0f : c_pre;                 // softmax in base 2: p = exp2(s*c - m)
 
     // multi-pass sums live in LDS between passes (touched once per pass), not in registers: [wave][FD][QF][lane] f32x4
     f32x4* totl = reinterpret_cast<f32x4*>(smem + 2 * (KBUF + VBUF)) + wave * (FD * QF * 64) + lane;
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(smem + 2 * (KBUF + VBUF) + 4 * FD * QF * 64 * 16);   // FAST: [2][KT] key-mask bytes of the staged tiles
     int nactive = 0, nseen = 0;
     for (int pass = 0; pass < p.npass; ++pass) {
         const AttnEntry& e0 = p.e[pass * ATT_MAXB + b];
@@ -166,6 +170,22 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
             }
             mode[f] = md;
         }
+        // FAST: the query side of the mask k-step (see tile_fast) and whether this wave holds a degenerate uniform-softmax query
+        u32x4 qaug[QF];
+        bool any_uniform = false;
+        if constexpr (FAUG) {
+            bool u = false;
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                qaug[f] = u32x4{0, 0, 0, 0};
+                if (g == 0) {
+                    qaug[f][0] = (mode[f] == 1 ? 0x3f80u : 0u) | (mode[f] == 2 ? 0x3f800000u : 0u);   // [wants mask!=0 | wants mask==0]
+                    qaug[f][1] = 0x3f80u;                                                              // out-of-range keys: always
+                }
+                u |= mode[f] == 3;
+            }
+            any_uniform = __any(u);
+        }
 
         f32x4 o[FD][QF];
         f32x4 lacc[QF];             // FAST: row sums of the fast tiles (ones-operand MFMA), replicated over the lane's 4 registers
@@ -181,9 +201,11 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
 
         // ---- tile staging: global -> registers (issued one tile ahead) -> LDS (double buffered) ----------------------
         u32x4 rk[NKC], rv[NVC];
+        uint32_t rmk = 0;           // FAST: mask byte of key k0 + tid of the tile in flight (threads < KT)
         const T* kbase = Kg + (long)en.kv_row * p.Sk * p.ldk + head * D;
         const T* vbase = Vg + ((long)en.kv_row * p.heads * D + head * D) * p.ldvt;
         auto issue = [&](int k0) {
+            if (FAUG && pass_masked && tid < KT) rmk = (k0 + tid < p.Sk) ? en.kmask[k0 + tid] : 0;
 #pragma unroll
             for (int i = 0; i < NKC; ++i) {
                 const int cid = tid + 256 * i;
@@ -211,6 +233,7 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
             }
         };
         auto stage = [&](int buf) {
+            if (FAUG && pass_masked && tid < KT) Ms[buf * KT + tid] = (uint8_t)rmk;
 #pragma unroll
             for (int i = 0; i < NKC; ++i) {
                 const int cid = tid + 256 * i;
@@ -235,43 +258,14 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int f = 0; f < QF; ++f) st[t][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-            u32x4 vpre[FAST ? NT / KPC : 1][FAST ? FD : 1];   // FAST: V^T fragments requested before the softmax (see tile_fast)
-            if constexpr (FAST) {
-                u32x4 ka[DSL][NT];
 #pragma unroll
-                for (int s = 0; s < DSL; ++s)
+            for (int s = 0; s < DSL; ++s) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const int krow = t * 16 + l15;
-                        ka[s][t] = *reinterpret_cast<const u32x4*>(Kb + krow * KROW + ((KSWZ ? ((4 * s + g) ^ (krow & 7)) : (4 * s + g)) << 4));
-                    }
-                __builtin_amdgcn_sched_barrier(0);
+                for (int t = 0; t < NT; ++t) {
+                    const int krow = t * 16 + l15;
+                    const u32x4 ka = *reinterpret_cast<const u32x4*>(Kb + krow * KROW + ((KSWZ ? ((4 * s + g) ^ (krow & 7)) : (4 * s + g)) << 4));
 #pragma unroll
-                for (int s = 0; s < DSL; ++s)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int f = 0; f < QF; ++f) DT<T>::mma(ka[s][t], qf[f][s], st[t][f]);
-#pragma unroll
-                for (int c = 0; c < NT / KPC; ++c)
-#pragma unroll
-                    for (int i = 0; i < FD; ++i) {
-                        const char* vrow = Vb + (i * 16 + l15) * VROW;
-                        const u32x2 lo = *(const volatile lds_u32x2_t*)(vrow + (32 * c + 4 * g) * SZ);   // volatile: keep two ds_read_b64 (a merged ds_read2_b64 banks mod 32: 2-way conflicts, half rate)
-                        const u32x2 hi = *(const volatile lds_u32x2_t*)(vrow + (32 * c + 16 + 4 * g) * SZ);
-                        vpre[c][i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-#pragma unroll
-                for (int s = 0; s < DSL; ++s) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const int krow = t * 16 + l15;
-                        const u32x4 ka = *reinterpret_cast<const u32x4*>(Kb + krow * KROW + ((KSWZ ? ((4 * s + g) ^ (krow & 7)) : (4 * s + g)) << 4));
-#pragma unroll
-                        for (int f = 0; f < QF; ++f) DT<T>::mma(ka, qf[f][s], st[t][f]);
-                    }
+                    for (int f = 0; f < QF; ++f) DT<T>::mma(ka, qf[f][s], st[t][f]);
                 }
             }
             // masked path: bit (4t+r) of `inr` = key in range, of `mk` = kmask byte != 0 (keys 16t+4g+r of this lane)
@@ -354,9 +348,7 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
                 for (int i = 0; i < FD; ++i) {
                     u32x4 va;
                     const char* vrow = Vb + (i * 16 + l15) * VROW;
-                    if constexpr (FAST) {
-                        va = vpre[c][i];
-                    } else if (KPC == 1) {
+                    if (KPC == 1) {
                         va = *reinterpret_cast<const u32x4*>(vrow + (16 * c + 4 * g) * SZ);
                     } else {
                         const u32x2 lo = *(const volatile lds_u32x2_t*)(vrow + (32 * c + 4 * g) * SZ);   // volatile: keep two ds_read_b64 (a merged ds_read2_b64 banks mod 32: 2-way conflicts, half rate)
@@ -370,16 +362,38 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
         };
 
 
-        // ---- FAST: one full, unmasked key tile (bf16) ---------------------------------------------------------------------
-        auto tile_fast = [&](int buf, bool first) {
+        // ---- FAST (bf16): one key tile.  AUG = the tile needs masking (key mask of a masked pass and / or keys past Sk): the mask
+        // rides on ONE extra MFMA k-step instead of per-element selects -- K gets three extra "dimensions" per key
+        // [mask==0 ? -BIG : 0, mask!=0 ? -BIG : 0, key>=Sk ? -BIG : 0] and Q the matching [wants mask!=0, wants mask==0, 1], so a
+        // disallowed score arrives as ~-1e30 and its exp2 is exactly 0 (masked tiles cost 2x an unmasked one with selects).
+        auto tile_fast = [&](int k0, int buf, bool first, auto aug_tag) {      // first: tile 0 of the pass (wave-uniform)
+            constexpr bool AUG = decltype(aug_tag)::value;
             const char* Kb = Ks + buf * KBUF;
             const char* Vb = Vs + buf * VBUF;
             f32x4 st[NT][QF];
+            bool unseen[QF];        // no allowed key of this query met so far (its reference m is still undefined)
 #pragma unroll
             for (int f = 0; f < QF; ++f) {
-                const float nm = first ? 0.f : -mrun[f];
+                unseen[f] = AUG ? (mrun[f] == NEG) : first;      // unmasked full tiles: every query meets keys in tile 0
+                const float nm = unseen[f] ? 0.f : -mrun[f];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) st[t][f] = f32x4{nm, nm, nm, nm};
+            }
+            if constexpr (AUG && FAUG) {
+                constexpr uint32_t NB = 0xf14au;                    // bf16(-1e30)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int kl = t * 16 + l15;
+                    const bool m1 = pass_masked && Ms[buf * KT + kl] != 0;
+                    const bool oor = k0 + kl >= p.Sk;
+                    u32x4 kaug = u32x4{0, 0, 0, 0};
+                    if (g == 0) {
+                        kaug[0] = pass_masked ? (m1 ? (NB << 16) : NB) : 0u;   // [mask==0 -> -BIG | mask!=0 -> -BIG]
+                        kaug[1] = oor ? NB : 0u;
+                    }
+#pragma unroll
+                    for (int f = 0; f < QF; ++f) DT<T>::mma(kaug, qaug[f], st[t][f]);
+                }
             }
             // all K fragments of the tile are requested before the first MFMA (the compiler otherwise emits read -> wait -> 2 MFMA
             // chains and every LDS latency is exposed); the V^T fragments are requested before the softmax and land under it
@@ -420,11 +434,13 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
                     tm = att_max3(tm, st[t][f][2], st[t][f][3]);
                 }
                 tm = att_max_groups(tm);
-                const bool need = first || tm > FAST_THR;
+                // first allowed key(s) of this query: reference m = tile max; later: only when the tile exceeds m by 2^FAST_THR.
+                // A tile whose keys are all disallowed for this query has tm ~ -1e30: nothing happens, its P is exactly 0.
+                const bool need = AUG ? (unseen[f] ? (tm > -1e29f) : (tm > FAST_THR)) : (first || tm > FAST_THR);
                 if (__any(need)) {            // re-reference: rare after the first tiles
                     const float delta = need ? tm : 0.f;
-                    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
-                    mrun[f] = first ? delta : mrun[f] + delta;
+                    const float alpha = unseen[f] ? 1.f : __builtin_amdgcn_exp2f(-delta);
+                    mrun[f] = need ? (unseen[f] ? delta : mrun[f] + delta) : mrun[f];
                     lrun[f] *= alpha;
                     lacc[f] *= alpha;
 #pragma unroll
@@ -460,12 +476,24 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
         for (int t = 0; t < ntiles; ++t) {
             const int k0 = t * KT, buf = t & 1;
             if (t + 1 < ntiles) issue(k0 + KT);
-            if (pass_masked || k0 + KT > p.Sk)
-                tile(k0, buf, std::true_type{});
-            else if constexpr (FAST)
-                tile_fast(buf, t == 0);
-            else
-                tile(k0, buf, std::false_type{});
+            if constexpr (FAUG) {
+                if (any_uniform)                               // degenerate uniform-softmax queries in this wave: generic tile
+                    tile(k0, buf, std::true_type{});
+                else if (pass_masked || k0 + KT > p.Sk)
+                    tile_fast(k0, buf, t == 0, std::true_type{});
+                else
+                    tile_fast(k0, buf, t == 0, std::false_type{});
+            } else if constexpr (FAST) {
+                if (pass_masked || k0 + KT > p.Sk)             // (no masks in this launch: only the ragged last tile comes here)
+                    tile(k0, buf, std::true_type{});
+                else
+                    tile_fast(k0, buf, t == 0, std::false_type{});
+            } else {
+                if (pass_masked || k0 + KT > p.Sk)
+                    tile(k0, buf, std::true_type{});
+                else
+                    tile(k0, buf, std::false_type{});
+            }
             if (t + 1 < ntiles) stage(buf ^ 1);
             __syncthreads();
         }

@@ -383,16 +383,16 @@ static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
     for (int i = 0; i < nc; ++i) {
         int rc = launch_bf16_cfg<AMODE>(s, d, cand[i]);      // warm (LDS opt-in, code load)
         if (rc) continue;
-        hipEventRecord(e0, s);
+        (void)hipEventRecord(e0, s);
         for (int r = 0; r < reps && !rc; ++r) rc = launch_bf16_cfg<AMODE>(s, d, cand[i]);
-        hipEventRecord(e1, s);
+        (void)hipEventRecord(e1, s);
         if (rc || hipEventSynchronize(e1) != hipSuccess) continue;
         float ms = 0.f;
-        hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
         if (ms < best_ms) { best_ms = ms; best = cand[i]; }
     }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     g_tuned[key] = best;
     static const bool verbose = getenv("FFN_IGEMM_TUNE_VERBOSE") != nullptr;
     if (verbose)
@@ -482,14 +482,14 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
 }
 
 // ---- attention ---------------------------------------------------------------------------------------------------
-template <typename T, int DP, int QF, int KT = 64, int OCC = 1>
+template <typename T, int DP, int QF, int KT = 64, int OCC = 1, bool MASKS = true>
 static int launch_attn(hipStream_t s, const ffn_attn_desc& d) {
     constexpr int SZ = sizeof(T);
     // double-buffered K and V^T tiles + the per-wave multi-pass accumulator
     constexpr int krow = (DP * SZ == 128) ? 128 : DP * SZ + 16;
-    constexpr int lds = 2 * (KT * krow + DP * (KT * SZ + 16)) + 4 * (DP / 16) * QF * 64 * 16;
+    constexpr int lds = 2 * (KT * krow + DP * (KT * SZ + 16)) + 4 * (DP / 16) * QF * 64 * 16 + 2 * KT;   // + key-mask bytes of the two staged tiles
     static_assert(lds <= 160 * 1024, "attention tile does not fit the 160 KiB LDS");
-    auto kern = attn_kernel<T, DP, QF, KT, OCC>;
+    auto kern = attn_kernel<T, DP, QF, KT, OCC, MASKS>;
     static bool lds_set = false;
     if (!lds_set) {
         int rc = set_lds(kern, lds);
@@ -522,9 +522,12 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
         if (D <= 80) return launch_attn<float, 80, 2>(s, *d);
         if (D <= 160) return launch_attn<float, 160, 1, 32>(s, *d);
     } else {
-        if (D <= 64) return launch_attn<bf16, 64, 2, 64, 2>(s, *d);
-        if (D <= 96) return launch_attn<bf16, 96, 2>(s, *d);
-        if (D <= 160) return launch_attn<bf16, 160, 1>(s, *d);
+        bool masks = false;      // any (pass, row) entry with a key mask -> the kernel variant with the mask-on-MFMA tile
+        for (int pi = 0; pi < d->npass; ++pi)
+            for (int b = 0; b < d->Bo; ++b) masks |= d->e[pi * FFN_ATT_MAXB + b].kmask != nullptr;
+        if (D <= 64) return masks ? launch_attn<bf16, 64, 2, 64, 2, true>(s, *d) : launch_attn<bf16, 64, 2, 64, 2, false>(s, *d);
+        if (D <= 96) return masks ? launch_attn<bf16, 96, 2, 64, 1, true>(s, *d) : launch_attn<bf16, 96, 2, 64, 1, false>(s, *d);
+        if (D <= 160) return masks ? launch_attn<bf16, 160, 1, 64, 1, true>(s, *d) : launch_attn<bf16, 160, 1, 64, 1, false>(s, *d);
     }
     return fail(FFN_ENOSYS, "attn: head dim %d not supported (max 160; use the GEMM path)", D);
 }

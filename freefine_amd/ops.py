@@ -71,10 +71,11 @@ def _timed(name, flops, nbytes, fn):
     return rc
 
 
-def _attn_name(q, dp, qf, Dh):
+def _attn_name(q, dp, qf, Dh, masks=True):
     kt = 32 if (q.dtype == torch.float32 and dp == 160) else 64
     occ = 2 if (q.dtype == torch.bfloat16 and dp == 64) else 1
-    return f"void attn_kernel<{_tname(q)}, {dp}, {qf}, {kt}, {occ}>(ffn_attn_desc)"
+    mk = "true" if (masks or q.dtype == torch.float32) else "false"      # bf16 launches without key masks run the leaner variant
+    return f"void attn_kernel<{_tname(q)}, {dp}, {qf}, {kt}, {occ}, {mk}>(ffn_attn_desc)"
 
 
 def _tname(t):
@@ -281,7 +282,8 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
             nterms = sum(1 for rows in passes for sp in rows[b0:b0 + nb] if sp is not None and (sp.w_const != 0.0 or sp.w_slope != 0.0))
             dp, qf = CT.c_int(), CT.c_int()
             lib.ffn_attn_variant(_dt(q), Dh, CT.byref(dp), CT.byref(qf))
-            L.check(_timed(_attn_name(q, dp.value, qf.value, Dh), 4.0 * nterms * S * Sk * Cq,
+            masks = any(sp is not None and sp.kmask is not None for rows in passes for sp in rows[b0:b0 + nb])
+            L.check(_timed(_attn_name(q, dp.value, qf.value, Dh, masks), 4.0 * nterms * S * Sk * Cq,
                            esz * nterms * (S * Cq + 2 * Sk * Cq) + esz * nb * S * Cq,
                            lambda: lib.ffn_attn(_stream(), _dt(q), CT.byref(d))), "ffn_attn")
     return out
