@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--no-dedup", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-ref-layout", dest="no_ref_layout", action="store_true", help="skip the extra one-image-per-UNet-batch measurement")
     ap.add_argument("--cpu-skip-vae", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=32)
     args = ap.parse_args()
@@ -261,6 +262,34 @@ def main():
                        "whole_path_tflops_per_gpu": round(f_img * value / world / 1e12, 1),
                        "whole_path_frac_of_mfma_peak": round(f_img * value / world / 1e12 / PEAK_TFLOPS[args.dtype], 4)},
         }
+        if args.batch > 1 and not args.no_ref_layout and world == 1:
+            # the reference's own batch layout (one image per UNet call: inversion B=2, guided denoising B=4 -- BASELINE.json configs[1]
+            # "batch=4"), same streams, measured beside the batched figure so both are on record
+            import copy
+            a1 = copy.copy(args)
+            a1.batch = 1
+
+            def worker1(j):
+                torch.cuda.set_device(device)
+                with torch.cuda.stream(streams[j]):
+                    for i in range(ref_steps):
+                        edit_once(models[j], a1, 5000 + 10 * j + i)
+                streams[j].synchronize()
+
+            ref_steps = 1
+            for j in range(len(models)):        # warm-up: graphs / tuning of the 2- and 3-row shapes
+                worker1(j)
+            ref_steps = 3
+            torch.cuda.synchronize()
+            t1 = time.time()
+            th = [threading.Thread(target=worker1, args=(j,)) for j in range(len(models))]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            torch.cuda.synchronize()
+            v1 = ref_steps * len(models) / (time.time() - t1)
+            line["config"]["reference_batch_layout"] = {
+                "value": round(v1, 4), "unit": "images/s", "images_per_unet_batch": 1, "unet_batch": 4, "concurrent_streams": args.concurrent,
+                "note": "same path, one image per UNet call (inversion B=2, guided B=4 logical / 3 physical rows)"}
         if not args.no_roofline:
             line["roofline"], table = roofline_leg(model, args)
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
