@@ -1,0 +1,52 @@
+"""GeoBench-2D batch inference on the MI355X engine -- same entry point as the reference's
+evaluation/FreeFine/freefine_batch_infer_2d.py (model setup :148-157, case loop :175-241, result JSON :243-262).
+
+    python evaluation/FreeFine/freefine_batch_infer_2d.py --base-dir <GeoBenchMeta> [--model <SD folder | synthetic:sd21-base>] [--batch 4]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 evaluation/FreeFine/freefine_batch_infer_2d.py --base-dir ...
+
+One process per GPU; cases are sharded like DistributedSampler(shuffle=False), results gathered with all_gather_object, rank 0
+writes <base-dir>/generated_results_freefine_2d.json.  The harness itself is freefine_amd/geobench.py."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+import torch  # noqa: E402
+
+from src.demo.model import DDIMScheduler, FreeFinePipeline  # noqa: E402
+from src.utils.attention import Attention_Modulator, register_attention_control  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--base-dir", required=True)
+    ap.add_argument("--model", default="synthetic:sd21-base")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="f32 = parity mode (the reference runs fp32 here), bf16 = fast mode")
+    ap.add_argument("--batch", type=int, default=4, help="cases edited together in one UNet batch")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank, local = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    device = torch.device(f"cuda:{local}")
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=device)
+    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    model = FreeFinePipeline.from_pretrained(args.model, torch_dtype=dtype, device=device).to(device)
+    model._progress_bar_config = {"disable": True}
+    model.scheduler = DDIMScheduler.from_config(model.scheduler.config)
+    controller = Attention_Modulator(start_layer=10)
+    model.controller = controller
+    register_attention_control(model, controller)
+    model.modify_unet_forward()
+    model.enable_attention_slicing()
+    model.enable_xformers_memory_efficient_attention()
+    model.unet.use_graph = True
+    from freefine_amd import geobench
+    geobench.run(model, args.base_dir, batch=args.batch, rank=rank, world=world)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+"""GeoBench-2D batch-inference harness on the MI355X engine: counterpart of the reference's driver
+/root/reference/evaluation/FreeFine/freefine_batch_infer_2d.py (case list :91-132, model setup :148-157, per-case
+pre-processing + FreeFine_generation call :175-236, result gather + JSON :243-262).
+
+Differences from the reference driver, all outside the arithmetic of an edit:
+  * cases are sharded with dist.shard_indices (DistributedSampler semantics) and the per-rank results gathered with
+    all_gather_object -- as the reference does -- but the process group is optional (single process when WORLD_SIZE is unset);
+  * `batch` cases are edited together through FreeFine_generation_batch (the reference must use batch size 1, :170);
+  * host pre-processing (PNG decode, resize, the affine coarse edit) runs in a prefetch thread so it overlaps the GPU;
+  * the reference reads `ori_mask` after using it in re_edit_2d (:196 vs :198, a NameError on the first case); here it is read first.
+"""
+import os
+import os.path as osp
+import queue
+import threading
+
+import numpy as np
+
+from src.utils.vis_utils import load_json, re_edit_2d, read_and_resize_img, read_and_resize_mask, save_img, save_json
+
+# the GeoBench-2D call parameters (freefine_batch_infer_2d.py:212-230)
+GEOBENCH_2D = dict(guidance_scale=7.5, eta=1.0, end_scale=0.0, end_step=50, num_step=50, start_step=35, seed=42)
+GEN_SUBDIR = "Geo-Bench-2D/Gen_results_FreeFine_2d"
+INP_SUBDIR = "Geo-Bench-2D/inp_img_blended"
+
+
+class CaseList:
+    """CustomDataset of the reference (:91-132): one case per data[da_n]['instances'][ins_id][edit_ins]; cases whose output PNG
+    exists are kept aside as existing results."""
+
+    def __init__(self, data, dst_dir_path_gen, check_exist=True):
+        self.cases, self.existing_results = [], []
+        self.dst = dst_dir_path_gen
+        for da_n, da in data.items():
+            for ins_id, cur in da.get("instances", {}).items():
+                for edit_ins, pack in cur.items():
+                    item = dict(da_n=da_n, ins_id=ins_id, edit_ins=edit_ins, **pack)
+                    path = self.expected_path(da_n, ins_id, edit_ins)
+                    if check_exist and osp.exists(path):
+                        item["gen_img_path"] = path
+                        self.existing_results.append(item)
+                    else:
+                        self.cases.append(item)
+
+    def expected_path(self, da_n, ins_id, edit_ins):
+        return osp.join(self.dst, str(da_n), str(ins_id), f"{edit_ins}.png")
+
+    def __len__(self):
+        return len(self.cases)
+
+    def __getitem__(self, i):
+        return self.cases[i]
+
+
+def load_case(case, dst_base, dsize=(512, 512)):
+    """host pre-processing of one case (:187-210): inputs of FreeFine_generation"""
+    inp_bg = read_and_resize_img(osp.join(dst_base, INP_SUBDIR, str(case["da_n"]), str(case["ins_id"]), "inp_img.png"), dsize)
+    ori_img = read_and_resize_img(case["ori_img_path"], dsize)
+    ori_mask = read_and_resize_mask(case["ori_mask_path"], dsize)
+    coarse, target_mask = re_edit_2d(ori_img, ori_mask, case["edit_param"], inp_bg)[:2]
+    return dict(ori_img=ori_img, ori_mask=ori_mask, coarse_input=coarse, target_mask=target_mask, guidance_text="",
+                draw_mask=np.ones_like(ori_mask), use_auto_draw=True, reduce_inp_artifacts=True, cons_area=target_mask)
+
+
+def _prefetch(cases, dst_base, depth, dsize):
+    q = queue.Queue(maxsize=depth)
+
+    def work():
+        for c in cases:
+            try:
+                q.put((c, load_case(c, dst_base, dsize), None))
+            except Exception as e:  # noqa: BLE001 -- reported on the consumer side with the case attached
+                q.put((c, None, e))
+        q.put(None)
+
+    threading.Thread(target=work, daemon=True).start()
+    while True:
+        item = q.get()
+        if item is None:
+            return
+        yield item
+
+
+def run(model, dst_base, batch=4, params=None, rank=0, world=1, check_exist=True, verbose=True, dsize=(512, 512)):
+    """edit every case of <dst_base>/annotations_2d.json that this rank owns; rank 0 writes generated_results_freefine_2d.json.
+    Returns the merged result list (on every rank)."""
+    from . import dist as FD
+    params = dict(GEOBENCH_2D, **(params or {}))
+    seed = params.pop("seed")
+    dst_gen = osp.join(dst_base, GEN_SUBDIR)
+    os.makedirs(dst_gen, exist_ok=True)
+    data = load_json(osp.join(dst_base, "annotations_2d.json"))
+    if data is None:
+        raise FileNotFoundError(osp.join(dst_base, "annotations_2d.json"))
+    cl = CaseList(data, dst_gen, check_exist)
+    mine = [cl[i] for i in FD.shard_indices(len(cl), rank, world)]
+    results = []
+    pending = []
+
+    def flush():
+        if not pending:
+            return
+        cases = [p[0] for p in pending]
+        inputs = [p[1] for p in pending]
+        if len(inputs) == 1:
+            kw = {k: v for k, v in inputs[0].items() if k not in ("ori_img", "ori_mask", "coarse_input", "target_mask", "guidance_text")}
+            imgs = [model.FreeFine_generation(inputs[0]["ori_img"], inputs[0]["ori_mask"], inputs[0]["coarse_input"], inputs[0]["target_mask"],
+                                              inputs[0]["guidance_text"], params["guidance_scale"], params["eta"], end_step=params["end_step"],
+                                              num_step=params["num_step"], start_step=params["start_step"], seed=seed,
+                                              end_scale=params["end_scale"], verbose=False, **kw)]
+        else:
+            imgs = model.FreeFine_generation_batch(inputs, params["guidance_scale"], params["eta"], end_step=params["end_step"],
+                                                   num_step=params["num_step"], start_step=params["start_step"], seeds=seed,
+                                                   end_scale=params["end_scale"], verbose=False)
+        for c, img in zip(cases, imgs):
+            path = save_img(img, dst_gen, c["da_n"], c["ins_id"], c["edit_ins"])
+            results.append(dict(c, gen_img_path=path, key=f'{c["da_n"]}/{c["ins_id"]}/{c["edit_ins"]}'))
+        pending.clear()
+
+    for case, inputs, err in _prefetch(mine, dst_base, 2 * batch, dsize):
+        if err is not None:
+            if verbose:
+                print(f'[geobench] skipped {case["da_n"]}/{case["ins_id"]}/{case["edit_ins"]}: {err}')
+            continue
+        pending.append((case, inputs))
+        if len(pending) == batch:
+            flush()
+    flush()
+    merged = FD.gather_results(results) if world > 1 else results
+    if rank == 0:
+        final = list(cl.existing_results) + merged
+        new_data = {}
+        for it in final:
+            it = {k: v for k, v in it.items() if k != "key"}
+            new_data.setdefault(it["da_n"], {"instances": {}})["instances"].setdefault(it["ins_id"], {})[it["edit_ins"]] = it
+        save_json(new_data, osp.join(dst_base, "generated_results_freefine_2d.json"))
+        if verbose:
+            print(f"Total images processed: {len(final)}")
+    return merged
+
+
+def make_synthetic_dataset(root, n_images=2, edits_per_image=2, size=96, seed=0):
+    """a GeoBenchMeta-shaped tree with seeded random images / rectangular instance masks / affine edit parameters (no dataset
+    exists offline): annotations_2d.json, source PNGs, Geo-Bench-2D/inp_img_blended/<da>/<ins>/inp_img.png."""
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    data = {}
+    for d in range(n_images):
+        da = f"{d:04d}"
+        img = rng.integers(0, 256, (size, size, 3), dtype=np.uint8)
+        os.makedirs(osp.join(root, "source", da), exist_ok=True)
+        ip = osp.join(root, "source", da, "img.png")
+        Image.fromarray(img).save(ip)
+        r0, c0 = int(rng.integers(size // 8, size // 3)), int(rng.integers(size // 8, size // 3))
+        mask = np.zeros((size, size), np.uint8)
+        mask[r0:r0 + size // 4, c0:c0 + size // 4] = 255
+        mp = osp.join(root, "source", da, "mask_0.png")
+        Image.fromarray(mask).save(mp)
+        inp_dir = osp.join(root, INP_SUBDIR, da, "0")
+        os.makedirs(inp_dir, exist_ok=True)
+        Image.fromarray(rng.integers(0, 256, (size, size, 3), dtype=np.uint8)).save(osp.join(inp_dir, "inp_img.png"))
+        edits = {}
+        for e in range(edits_per_image):
+            dx, dy = int(rng.integers(4, size // 4)), int(rng.integers(-4, size // 6))
+            edits[str(e)] = dict(ori_img_path=ip, ori_mask_path=mp, edit_param=[dx, dy, 0, 0, 0, float(rng.integers(-20, 20)), 1.0, 1.0, 1.0],
+                                 edit_prompt="move")
+        data[da] = {"instances": {"0": edits}}
+    save_json(data, osp.join(root, "annotations_2d.json"))
+    return data

@@ -176,3 +176,24 @@ def test_bf16_fast_mode_deviation_reported(gpu):
     dev = traj_dev(model.last_intermediates, g[f"{name}_traj"])
     print(f"bf16 fast mode: latent L-inf vs reference golden {dev:.3e}")
     assert dev < 0.5
+
+
+def test_geobench_harness_on_gpu(gpu, tmp_path):
+    """the GeoBench-2D harness (freefine_amd/geobench.py: case list, host pre-processing without cv2, batches of cases through
+    FreeFine_generation_batch, PNG + JSON results) end to end on a synthetic GeoBenchMeta tree; one case re-run directly."""
+    from PIL import Image
+    from freefine_amd import geobench
+    root = str(tmp_path / "geo")
+    geobench.make_synthetic_dataset(root, n_images=2, edits_per_image=2, size=128, seed=3)
+    model = make_pipe(gpu, "tiny", "edit", graph=True)
+    params = dict(num_step=10, start_step=7, end_step=10)
+    res = geobench.run(model, root, batch=3, params=params, dsize=(128, 128), verbose=False)      # 4 cases: a batch of 3, then a single one
+    assert len(res) == 4 and os.path.exists(os.path.join(root, "generated_results_freefine_2d.json"))
+    case = res[1]
+    inputs = geobench.load_case(case, root, (128, 128))
+    direct = model.FreeFine_generation(inputs["ori_img"], inputs["ori_mask"], inputs["coarse_input"], inputs["target_mask"], "", 7.5, 1.0,
+                                       end_step=10, num_step=10, start_step=7, seed=42, end_scale=0.0, draw_mask=inputs["draw_mask"],
+                                       use_auto_draw=True, reduce_inp_artifacts=True, cons_area=inputs["cons_area"])
+    saved = np.asarray(Image.open(case["gen_img_path"]))
+    assert saved.shape == (128, 128, 3) and np.isfinite(direct.astype(float)).all()
+    assert np.abs(saved.astype(int) - direct.astype(int)).max() <= 1
