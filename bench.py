@@ -193,11 +193,19 @@ def main():
     args = ap.parse_args()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    # smoke-testing the multi-rank path on a 1-GPU box: FFN_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0 and uses gloo (RCCL refuses
+    # two ranks on one device); the measured number is then meaningless, only the code path is exercised
+    share = os.environ.get("FFN_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device(f"cuda:{local}")
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     from freefine_amd import _lib
     _lib.load()   # no fallback: fail loudly if the HIP extension is missing
     model = build_model(args, device, rank, world)
