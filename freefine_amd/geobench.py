@@ -139,7 +139,83 @@ def run(model, dst_base, batch=4, params=None, rank=0, world=1, check_exist=True
     return merged
 
 
-def make_synthetic_dataset(root, n_images=2, edits_per_image=2, size=96, seed=0):
+# ---------------------------------------------------------------------------------------------------------------------
+# stage 1 of GeoBench-2D: object removal / background generation (freefine_batch_infer_bggen_2d.py) -- produces the
+# Geo-Bench-2D/inp_img_{blended,no_blend}/<da>/<ins>/inp_img.png files the edit stage pastes the moved object onto
+# ---------------------------------------------------------------------------------------------------------------------
+GEOBENCH_BGGEN = dict(guidance_text="empty scene", guidance_scale=7.5, eta=1.0, end_scale=0.5, end_step=35, num_step=50, start_step=1)
+
+
+class InpaintCaseList:
+    """CustomDatasetInpaint (:39-87): one case per (image, instance), inputs taken from the instance's first edit entry"""
+
+    def __init__(self, data, dst_dir, check_exist=True):
+        self.cases, self.existing_results = [], []
+        for da_n, da in data.items():
+            for ins_id, cur in da.get("instances", {}).items():
+                if not cur:
+                    continue
+                item = dict(da_n=da_n, ins_id=ins_id, **cur[next(iter(cur))])
+                path = osp.join(dst_dir, str(da_n), str(ins_id), "inp_img.png")
+                if check_exist and osp.exists(path):
+                    self.existing_results.append(dict(item, gen_img_path=path))
+                else:
+                    self.cases.append(item)
+
+    def __len__(self):
+        return len(self.cases)
+
+    def __getitem__(self, i):
+        return self.cases[i]
+
+
+def blend_with_original(ori_img, hole_mask, generated):
+    """the driver's optional paste-back (:186-190, "from brushnet"): cv2.GaussianBlur(mask, (21,21), 0) -> sigma 3.5 (OpenCV's
+    0.3*((k-1)*0.5-1)+0.8), radius 10, reflect-101 border; mask_np = 1-(1-m)(1-blur/255); out = ori*(1-mask_np) + gen*mask_np.
+    The mask is {0,1} uint8, so blur/255 is ~0.004 at most: the blend is the hard mask to within half a percent -- kept as is."""
+    from scipy import ndimage
+    m = hole_mask.astype(np.float64)
+    blur = np.rint(ndimage.gaussian_filter(m, sigma=(3.5, 3.5) + (0,) * (m.ndim - 2), mode="mirror", truncate=10 / 3.5)) / 255
+    mask_np = 1 - (1 - m) * (1 - blur)
+    return (ori_img * (1 - mask_np) + generated * mask_np).astype(generated.dtype)
+
+
+def run_bggen(model, dst_base, blending=True, params=None, rank=0, world=1, check_exist=True, verbose=True, dsize=(512, 512), seed=None):
+    """remove the annotated object of every (image, instance) with FreeFine_background_generation (model must carry the bg-gen hook:
+    register_attention_control_4bggen).  seed=None draws a fresh seed per case like the reference (:162)."""
+    import random
+    from src.utils.vis_utils import read_and_resize_mask_with_dilation
+    from . import dist as FD
+    params = dict(GEOBENCH_BGGEN, **(params or {}))
+    out_dir = osp.join(dst_base, INP_SUBDIR if blending else "Geo-Bench-2D/inp_img_no_blend")
+    os.makedirs(out_dir, exist_ok=True)
+    data = load_json(osp.join(dst_base, "annotations_2d.json"))
+    if data is None:
+        raise FileNotFoundError(osp.join(dst_base, "annotations_2d.json"))
+    cl = InpaintCaseList(data, out_dir, check_exist)
+    done = []
+    for i in FD.shard_indices(len(cl), rank, world):
+        c = cl[i]
+        ori_img = read_and_resize_img(c["ori_img_path"], dsize)
+        hole = read_and_resize_mask_with_dilation(c["ori_mask_path"], dsize, dilation_factor=30, forbit_area=None)
+        s = random.randint(0, 10 ** 16) if seed is None else seed
+        gen = model.FreeFine_background_generation(ori_img, hole, params["guidance_text"], params["guidance_scale"], params["eta"],
+                                                   end_step=params["end_step"], num_step=params["num_step"], start_step=params["start_step"],
+                                                   end_scale=params["end_scale"], seed=s % (2 ** 63), verbose=False)
+        if blending:
+            gen = blend_with_original(ori_img, hole, gen)
+        d = osp.join(out_dir, str(c["da_n"]), str(c["ins_id"]))
+        os.makedirs(d, exist_ok=True)
+        from PIL import Image
+        Image.fromarray(gen).save(osp.join(d, "inp_img.png"))
+        done.append(dict(key=f'{c["da_n"]}/{c["ins_id"]}', da_n=c["da_n"], ins_id=c["ins_id"], inp_img_path=osp.join(d, "inp_img.png")))
+    merged = FD.gather_results(done) if world > 1 else done
+    if verbose and rank == 0:
+        print(f"background images generated: {len(merged)} (+{len(cl.existing_results)} existing)")
+    return merged
+
+
+def make_synthetic_dataset(root, n_images=2, edits_per_image=2, size=96, seed=0, with_backgrounds=True):
     """a GeoBenchMeta-shaped tree with seeded random images / rectangular instance masks / affine edit parameters (no dataset
     exists offline): annotations_2d.json, source PNGs, Geo-Bench-2D/inp_img_blended/<da>/<ins>/inp_img.png."""
     from PIL import Image
@@ -156,9 +232,10 @@ def make_synthetic_dataset(root, n_images=2, edits_per_image=2, size=96, seed=0)
         mask[r0:r0 + size // 4, c0:c0 + size // 4] = 255
         mp = osp.join(root, "source", da, "mask_0.png")
         Image.fromarray(mask).save(mp)
-        inp_dir = osp.join(root, INP_SUBDIR, da, "0")
-        os.makedirs(inp_dir, exist_ok=True)
-        Image.fromarray(rng.integers(0, 256, (size, size, 3), dtype=np.uint8)).save(osp.join(inp_dir, "inp_img.png"))
+        if with_backgrounds:
+            inp_dir = osp.join(root, INP_SUBDIR, da, "0")
+            os.makedirs(inp_dir, exist_ok=True)
+            Image.fromarray(rng.integers(0, 256, (size, size, 3), dtype=np.uint8)).save(osp.join(inp_dir, "inp_img.png"))
         edits = {}
         for e in range(edits_per_image):
             dx, dy = int(rng.integers(4, size // 4)), int(rng.integers(-4, size // 6))

@@ -184,7 +184,13 @@ def test_geobench_harness_on_gpu(gpu, tmp_path):
     from PIL import Image
     from freefine_amd import geobench
     root = str(tmp_path / "geo")
-    geobench.make_synthetic_dataset(root, n_images=2, edits_per_image=2, size=128, seed=3)
+    geobench.make_synthetic_dataset(root, n_images=2, edits_per_image=2, size=128, seed=3, with_backgrounds=False)
+    # stage 1: object removal writes the background images stage 2 pastes the moved object onto
+    bg_model = make_pipe(gpu, "tiny", "bggen", graph=True)
+    bgs = geobench.run_bggen(bg_model, root, blending=True, params=dict(num_step=10, start_step=1, end_step=6), dsize=(128, 128), seed=7,
+                             verbose=False)
+    assert len(bgs) == 2 and all(os.path.exists(b["inp_img_path"]) for b in bgs)
+    assert geobench.run_bggen(bg_model, root, params=dict(num_step=10, start_step=1, end_step=6), dsize=(128, 128), seed=7, verbose=False) == []
     model = make_pipe(gpu, "tiny", "edit", graph=True)
     params = dict(num_step=10, start_step=7, end_step=10)
     res = geobench.run(model, root, batch=3, params=params, dsize=(128, 128), verbose=False)      # 4 cases: a batch of 3, then a single one
