@@ -240,10 +240,10 @@ extern "C" int ffn_attn_variant(int dtype, int D, int* dp, int* qf) {
 // runs the N = 320 convs at 850-1000 TFLOP/s where 128x128 -- 17% of its third column tile wasted -- gives 690-760; 256x256
 // reaches 1190 on N = 1280 but loses 20% on N = 640).  So the first time a problem shape is seen outside stream capture, the
 // few plausible configurations are timed on the caller's stream with the caller's buffers and the winner is cached.
-enum { CFG_64x64, CFG_128x64, CFG_128x128_8, CFG_128x128_16, CFG_256x128, CFG_256x256, CFG_128x320, CFG_128x160, CFG_COUNT };
+enum { CFG_64x64, CFG_128x64, CFG_128x128_8, CFG_128x128_16, CFG_256x128, CFG_256x256, CFG_128x320, CFG_128x160, CFG_192x320, CFG_COUNT };
 struct IgCfgInfo { int bm, bn, nwm, nwn; };
 static const IgCfgInfo kCfg[CFG_COUNT] = {{64, 64, 2, 2}, {128, 64, 4, 2}, {128, 128, 2, 4}, {128, 128, 4, 4},
-                                          {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 320, 4, 4}, {128, 160, 4, 2}};
+                                          {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 320, 4, 4}, {128, 160, 4, 2}, {192, 320, 4, 4}};
 struct IgChoice { int cfg, splitk; };
 
 template <int AMODE>
@@ -268,6 +268,7 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
         FFN_CFG_CASE(CFG_256x256, 256, 256, 4, 4)
         FFN_CFG_CASE(CFG_128x320, 128, 320, 4, 4)
         FFN_CFG_CASE(CFG_128x160, 128, 160, 4, 2)
+        FFN_CFG_CASE(CFG_192x320, 192, 320, 4, 4)
         default: return fail(FFN_EINVAL, "igemm: bad configuration %d", ch.cfg);
     }
 #undef FFN_CFG_CASE
@@ -321,7 +322,7 @@ static int candidates_for(const ffn_igemm_desc& d, IgChoice* out, int cap) {
     const long per = (long)d.M * d.N * 4;
     for (int cfg = 0; cfg < CFG_COUNT; ++cfg) {
         const IgCfgInfo& c = kCfg[cfg];
-        if ((cfg == CFG_128x320 || cfg == CFG_128x160) && (d.flags & FFN_IG_GEGLU)) continue;   // odd number of column blocks per wave
+        if ((cfg == CFG_128x320 || cfg == CFG_128x160 || cfg == CFG_192x320) && (d.flags & FFN_IG_GEGLU)) continue;   // odd number of column blocks per wave
         if (c.bm > 64 && c.bm >= 2 * d.M) continue;                                // tile mostly empty
         if (c.bn > 64 && c.bn >= 2 * d.N) continue;
         if (cfg == CFG_64x64 && (long)d.M * d.N > (1l << 22)) continue;
