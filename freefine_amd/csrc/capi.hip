@@ -240,12 +240,32 @@ extern "C" int ffn_attn_variant(int dtype, int D, int* dp, int* qf) {
 // runs the N = 320 convs at 850-1000 TFLOP/s where 128x128 -- 17% of its third column tile wasted -- gives 690-760; 256x256
 // reaches 1190 on N = 1280 but loses 20% on N = 640).  So the first time a problem shape is seen outside stream capture, the
 // few plausible configurations are timed on the caller's stream with the caller's buffers and the winner is cached.
-enum { CFG_64x64, CFG_128x64, CFG_128x128_8, CFG_128x128_16, CFG_256x128, CFG_256x256, CFG_128x320, CFG_128x160, CFG_192x320, CFG_COUNT };
+enum { CFG_64x64, CFG_128x64, CFG_128x128_8, CFG_128x128_16, CFG_256x128, CFG_256x256, CFG_128x320, CFG_128x160, CFG_192x320, CFG_H_128x320, CFG_H_256x128, CFG_H_256x256, CFG_H_128x128, CFG_COUNT };
 struct IgCfgInfo { int bm, bn, nwm, nwn; };
 static const IgCfgInfo kCfg[CFG_COUNT] = {{64, 64, 2, 2}, {128, 64, 4, 2}, {128, 128, 2, 4}, {128, 128, 4, 4},
-                                          {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 320, 4, 4}, {128, 160, 4, 2}, {192, 320, 4, 4}};
+                                          {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 320, 4, 4}, {128, 160, 4, 2}, {192, 320, 4, 4},
+                                          {128, 320, 4, 4}, {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 128, 4, 4}};   // last four: halo kernel (3x3 stride-1 convs)
 struct IgChoice { int cfg, splitk; };
 
+static bool is_halo_cfg(int cfg) { return cfg == CFG_H_128x320 || cfg == CFG_H_256x128 || cfg == CFG_H_256x256 || cfg == CFG_H_128x128; }
+// LDS bytes of ONE halo buffer of the halo conv kernel for tile height bm, or 0 if the problem does not fit the kernel: 3x3,
+// stride 1, pad 1, no upsample, whole 64-channel chunks, and a tile = whole image rows (W <= bm) or a piece of one row
+static int halo_bytes_for(const ffn_igemm_desc& d, int bm) {
+    if (!d.conv || d.stride != 1 || d.upsample || d.pad != 1 || d.Hin != d.Hout || d.Win != d.Wout) return 0;
+    if (d.Cin % 64 != 0 || d.Cin > 30000 || d.K != 9 * d.Cin || d.M % bm != 0) return 0;
+    const int H = d.Hin, W = d.Win;
+    int tw, tr;
+    if (W <= bm) {
+        if (bm % W != 0 || (H * W) % bm != 0) return 0;
+        tw = W; tr = bm / W;
+    } else {
+        if (W % bm != 0) return 0;
+        tw = bm; tr = 1;
+    }
+    const int nq = ((tr + 2) * (tw + 2) + 7) / 8;
+    if (nq > 4 * 16) return 0;                      // 4 halo wave-instructions per wave, 16 waves
+    return nq * 8 * 128;
+}
 template <int AMODE>
 static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) {
     const IgCfgInfo& c = kCfg[ch.cfg];
@@ -269,6 +289,37 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
         FFN_CFG_CASE(CFG_128x320, 128, 320, 4, 4)
         FFN_CFG_CASE(CFG_128x160, 128, 160, 4, 2)
         FFN_CFG_CASE(CFG_192x320, 192, 320, 4, 4)
+        case CFG_H_128x320:
+        case CFG_H_256x128:
+        case CFG_H_256x256:
+        case CFG_H_128x128:
+            if constexpr (AMODE == AMODE_CONV3) {
+                const int hb = halo_bytes_for(d, c.bm);
+                if (hb <= 0 || ch.splitk != 1) return fail(FFN_EINVAL, "igemm: halo kernel not applicable");
+                const int hlds = 2 * hb + 2 * c.bn * 128;
+                const int nt = (d.M / c.bm) * ((d.N + c.bn - 1) / c.bn);
+                (void)hipGetLastError();
+                if (ch.cfg == CFG_H_128x320) {
+                    auto kern = igemm_halo_kernel<bf16, 128, 320, 4, 4>;
+                    if ((rc = set_lds(kern, hlds))) return rc;
+                    hipLaunchKernelGGL(kern, dim3(nt), dim3(threads), hlds, s, d, hb);
+                } else if (ch.cfg == CFG_H_256x128) {
+                    auto kern = igemm_halo_kernel<bf16, 256, 128, 4, 4>;
+                    if ((rc = set_lds(kern, hlds))) return rc;
+                    hipLaunchKernelGGL(kern, dim3(nt), dim3(threads), hlds, s, d, hb);
+                } else if (ch.cfg == CFG_H_256x256) {
+                    auto kern = igemm_halo_kernel<bf16, 256, 256, 4, 4>;
+                    if ((rc = set_lds(kern, hlds))) return rc;
+                    hipLaunchKernelGGL(kern, dim3(nt), dim3(threads), hlds, s, d, hb);
+                } else {
+                    auto kern = igemm_halo_kernel<bf16, 128, 128, 4, 4>;
+                    if ((rc = set_lds(kern, hlds))) return rc;
+                    hipLaunchKernelGGL(kern, dim3(nt), dim3(threads), hlds, s, d, hb);
+                }
+                return check_launch("igemm(halo)");
+            } else {
+                return fail(FFN_EINVAL, "igemm: halo configurations are for 3x3 convolutions");
+            }
         default: return fail(FFN_EINVAL, "igemm: bad configuration %d", ch.cfg);
     }
 #undef FFN_CFG_CASE
@@ -323,13 +374,19 @@ static int candidates_for(const ffn_igemm_desc& d, IgChoice* out, int cap) {
     for (int cfg = 0; cfg < CFG_COUNT; ++cfg) {
         const IgCfgInfo& c = kCfg[cfg];
         if ((cfg == CFG_128x320 || cfg == CFG_128x160 || cfg == CFG_192x320) && (d.flags & FFN_IG_GEGLU)) continue;   // odd number of column blocks per wave
+        if (is_halo_cfg(cfg)) {
+            const int hb = halo_bytes_for(d, c.bm);
+            if (hb <= 0 || d.splitk > 1 || 2 * hb + 2 * c.bn * 128 > 160 * 1024) continue;
+            if ((cfg == CFG_H_128x320) && (d.flags & FFN_IG_GEGLU)) continue;
+        }
+        const bool halo = is_halo_cfg(cfg);
         if (c.bm > 64 && c.bm >= 2 * d.M) continue;                                // tile mostly empty
         if (c.bn > 64 && c.bn >= 2 * d.N) continue;
         if (cfg == CFG_64x64 && (long)d.M * d.N > (1l << 22)) continue;
         const long tiles = (long)((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn);
         int splits[3] = {1, 0, 0};
         if (d.splitk > 1) splits[0] = d.splitk;
-        else if (can_split(d)) {
+        else if (can_split(d) && !halo) {
             for (int t = 0; t < 2; ++t) {
                 int sgo = (int)(((t ? 512 : 256) + tiles / 2) / tiles);
                 if (sgo > nk / 4) sgo = nk / 4;
@@ -416,6 +473,10 @@ extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d, char* b
     if (dtype == FFN_BF16 && !(d->flags & FFN_IG_OUT_TRANSPOSED)) {      // the tuned (or, untuned, rule-based) bf16 configuration
         if (!tuned_lookup(*d, &ch)) ch = heuristic_choice(*d);
         const IgCfgInfo& c = kCfg[ch.cfg];
+        if (is_halo_cfg(ch.cfg)) {
+            snprintf(buf, len, "void igemm_halo_kernel<bf16, %d, %d, %d, %d>(ffn_igemm_desc, int)", c.bm, c.bn, c.nwm, c.nwn);
+            return FFN_OK;
+        }
         const bool fastk = d->conv ? (d->Cin % 64 == 0 && d->Cin <= 30000) : (d->K % 64 == 0 && d->K <= 30000);
         snprintf(buf, len, "void igemm_glds_kernel<bf16, %d, %d, %d, true, 2, %d, %d, %s>(ffn_igemm_desc)", c.bm, c.bn, d->conv ? 1 : 0, c.nwm, c.nwn,
                  fastk ? "true" : "false");

@@ -578,6 +578,152 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// igemm_halo_kernel: 3x3 / stride 1 / pad 1 convolution whose A operand is staged ONCE per 64-channel chunk as the tile's
+// pixel HALO and re-read from LDS by all nine taps.  The im2col kernels above move (BM + BN) * 128 B into LDS per (tap, chunk)
+// stage although the nine taps of a chunk read almost the same input pixels; they are bound by the L2 -> LDS path (measured:
+// 10.9 TB/s, 44 % MFMA busy on the 128x320 tile), so bytes are what count.  Per chunk this kernel moves
+// (rows+2)*(width+2)*128 B of A instead of 9*BM*128 B (128-pixel tile on a 64-wide image: 33 KB instead of 144 KB).
+//   tile   = BM consecutive output pixels of ONE image = `TR` whole image rows (W <= BM, BM % W == 0, H*W % BM == 0) or a
+//            BM-wide piece of one row (W % BM == 0); the caller checks this
+//   K loop = (chunk c, tap t), tap fastest: the weight stage of (c, t) is W[:, t*Cin + c*64 .. +64) of the usual packed
+//            layout -- no repacking, only a different walk; fp32 summation order differs from the im2col kernels
+//   LDS    = 2 halo buffers [slots][128 B] (slot = halo pixel, 16-byte chunks XOR-swizzled by slot & 7 like the tile rows of
+//            the other kernels; chunk c+1 loads while chunk c is multiplied) + the 2-stage weight ring [BN][128 B]
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int NWM, int NWN>
+__global__ __launch_bounds__(64 * NWM * NWN) void igemm_halo_kernel(const IgemmParams p, int halo_bytes) {
+    constexpr int EPC = DT<T>::EPC;
+    constexpr int BKE = 8 * EPC;
+    constexpr int NW = NWM * NWN;
+    constexpr int WM = BM / NWM, WN = BN / NWN;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int GB = BN / 8, NB = (GB + NW - 1) / NW;
+    constexpr int NI = 4;                       // halo wave-instructions per wave per chunk (caller guarantees enough)
+    static_assert(WM % 16 == 0 && WN % 16 == 0, "tile / wave grid mismatch");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Hs = smem;                            // [2][halo_bytes]
+    char* Bs = smem + 2 * halo_bytes;           // [2][BN][128]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int lrow = lane >> 3;
+    const int H = p.Hin, W = p.Win, Cin = p.Cin;
+
+    const int ntn = (p.N + BN - 1) / BN;
+    const int ntm = p.M / BM;
+    const int L = xcd_remap(blockIdx.x, ntm * ntn);
+    const int m0 = (L / ntn) * BM, n0 = (L % ntn) * BN;
+    // tile geometry
+    const int TW = W <= BM ? W : BM, TR = BM / TW;
+    const int HW2 = TW + 2, NSLOT = (TR + 2) * HW2, NQ = (NSLOT + 7) >> 3;
+    const int img = m0 / (H * W), rem = m0 - img * (H * W);
+    const int y0 = rem / W, x0 = rem - y0 * W;
+
+    const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A);
+    const T* __restrict__ Wg = reinterpret_cast<const T*>(p.W);
+    const char* zpage = reinterpret_cast<const char*>(g_zero_page);
+
+    // halo loader: wave-instruction q covers slots 8q .. 8q+7 (lane>>3 picks the slot, lane&7 the chunk position; the lane
+    // fetches source chunk (lane&7) ^ (slot&7)); running pointers, +128 B per chunk, like the streaming loader
+    const char* h_cur[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int slot = 8 * (wave + NW * i) + lrow;
+        const int hy = slot / HW2, hx = slot - hy * HW2;
+        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+        const bool ok = slot < NSLOT && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        const int csrc = (lane & 7) ^ (slot & 7);
+        h_cur[i] = ok ? reinterpret_cast<const char*>(Ag + ((long)(img * H + yy) * W + xx) * Cin + csrc * EPC) : zpage + csrc * 16;
+    }
+    auto issue_halo = [&](int hbuf) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (wave + NW * i >= NQ) continue;
+            __builtin_amdgcn_global_load_lds((gptr_t)h_cur[i], (lptr_t)(Hs + hbuf * halo_bytes + (8 * (wave + NW * i)) * 128), 16, 0, 0);
+            h_cur[i] += 128;
+        }
+    };
+    // weight loader: stage (c, t) = columns [t*Cin + c*64, +64); pointer walk +Cin per tap, -(8*Cin) + 64 at the chunk wrap
+    const char* b_cur[NB];
+    const int wsrc = (lane & 7) ^ lrow;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int n = n0 + 8 * (wave + NW * i) + lrow;
+        b_cur[i] = (n < p.N) ? reinterpret_cast<const char*>(Wg + (long)n * p.Kpad + wsrc * EPC) : nullptr;
+    }
+    const long tap_step = (long)Cin * sizeof(T), wrap_step = 128 - 8 * tap_step;
+    auto issue_w = [&](int wbuf, bool last_tap) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (GB % NW != 0 && wave + NW * i >= GB) continue;
+            const char* src = b_cur[i] ? b_cur[i] : zpage + wsrc * 16;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + wbuf * BN * 128 + (8 * (wave + NW * i)) * 128), 16, 0, 0);
+            if (b_cur[i]) b_cur[i] += last_tap ? wrap_step : tap_step;
+        }
+    };
+
+    // per-fragment halo slot of this lane's output pixel at tap (0,0)
+    int slot0[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int ml = wm * WM + i * 16 + l15;
+        const int r = ml / TW;
+        slot0[i] = r * HW2 + (ml - r * TW);
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int hbuf, int wbuf, int tapoff) {
+        const char* Hb = Hs + hbuf * halo_bytes;
+        const char* Bb = Bs + wbuf * BN * 128;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 fa[FM], fb[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int slot = slot0[i] + tapoff;
+                fa[i] = *reinterpret_cast<const u32x4*>(Hb + slot * 128 + (((4 * s + g) ^ (slot & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int row = wn * WN + j * 16 + l15;
+                fb[j] = *reinterpret_cast<const u32x4*>(Bb + row * 128 + (((4 * s + g) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) DT<T>::mma(fb[j], fa[i], acc[i][j]);
+        }
+    };
+
+    const int nc = Cin / BKE;
+    issue_halo(0);
+    issue_w(0, false);
+    int hbuf = 0, wbuf = 0;
+    for (int c = 0; c < nc; ++c) {
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();       // this stage's weights (and, at t == 0, this chunk's halo) visible; previous stage's buffers free
+            if (t < 8 || c + 1 < nc) issue_w(wbuf ^ 1, t == 7);      // the stage being requested is (c, t+1), or (c+1, 0) after tap 8
+            if (t == 0 && c + 1 < nc) issue_halo(hbuf ^ 1);
+            const int ky = t / 3;
+            compute(hbuf, wbuf, ky * HW2 + (t - 3 * ky));
+            wbuf ^= 1;
+        }
+        hbuf ^= 1;
+    }
+    igemm_epilogue<T, FM, FN, true>(p, acc, m0 + wm * WM, n0 + wn * WN, l15, g);
+}
+
 // split-K finish: out[m, n..n+3] = epilogue(sum_s slab[s][m][n..n+3])  (same epilogue as the SWAP path of igemm_kernel)
 template <typename T>
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmParams p, int splitk) {
