@@ -171,13 +171,15 @@ def test_attention_plain(gpu, dtype, S, Sk, heads, D):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_attention_tca_edit(gpu, dtype):
+@pytest.mark.parametrize("S,heads,D", [(192, 5, 64), (200, 8, 40), (144, 4, 80), (136, 2, 160)])
+def test_attention_tca_edit(gpu, dtype, S, heads, D):
     """TCA edit branch: K/V from the reference rows, per-key source mask, per-query selector, tiled-head rule,
-    context-guidance blend with the self pass (weights from a device scalar)."""
+    context-guidance blend with the self pass (weights from a device scalar); SD-2.1 (d=64) and SD-1.5 (d=40/80/160) head sizes,
+    ragged S (mask-on-MFMA tile with out-of-range keys)."""
     from freefine_amd import ops
     from freefine_amd._lib import ATT_HEAD_RULE
     g = torch.Generator().manual_seed(21)
-    B, S, heads, D = 4, 192, 5, 64
+    B = 4
     Cc = heads * D
     q = rnd((B, S, Cc), dtype, gpu, g)
     k = rnd((B, S, Cc), dtype, gpu, g)
