@@ -78,6 +78,7 @@ SYMBOLS = {
     "ffn_igemm_kernel_name": (_i, [_i, C.POINTER(IgemmDesc), C.c_char_p, _i]),
     "ffn_attn_variant": (_i, [_i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ffn_gn_nchunk": (_i, [_i]),
+    "ffn_gn_fused": (_i, [_i, _i, _i, _i]),
     "ffn_gn_stats": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "ffn_gn_apply": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "ffn_groupnorm": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),

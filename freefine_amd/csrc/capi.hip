@@ -601,6 +601,15 @@ extern "C" int ffn_gn_nchunk(int HW) {
     if (n > 256) n = 256;
     return n;
 }
+// one fused launch (statistics + normalise + SiLU by the workgroup that owns a (row, group) slice) or stats + finalize + apply?
+// Measured (tools/bench_kernels.py --only norm): the fused kernel reads 20-120 byte per-pixel group segments, so it only wins while
+// the tensor is small enough for launch latency to dominate -- up to 16x16 positions at any batch, 32x32 below ~3M elements.
+extern "C" int ffn_gn_fused(int B, int HW, int C, int G) {
+    const long slice = (long)HW * (C / (G > 0 ? G : 1));
+    if (slice > 131072) return 0;
+    if (HW <= 256) return 1;
+    return (HW <= 1024 && (long)B * HW * C <= 3000000l) ? 1 : 0;
+}
 extern "C" int ffn_groupnorm(void* stream, int dtype, const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C,
                              int G, float eps, int silu, float* partial_ws, float* scale, float* shift) {
     REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "groupnorm: bad dtype");
@@ -608,7 +617,8 @@ extern "C" int ffn_groupnorm(void* stream, int dtype, const void* x, void* y, co
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long slice = (long)HW * (C / G);
     (void)slice;
-    if (HW <= 1024 && slice <= 131072) {   // one workgroup owns a whole (batch, group) slice: statistics + normalise + SiLU in ONE launch
+    const bool fused = ffn_gn_fused(B, HW, C, G) != 0;
+    if (fused) {   // one workgroup owns a whole (batch, group) slice: statistics + normalise + SiLU in ONE launch
                                            // (measured: wins up to 32x32 latents; at 64x64 the 20-60 byte per-pixel group segments coalesce badly)
         dim3 grid(G, B);
         if (dtype == FFN_F32) {

@@ -111,6 +111,8 @@ int ffn_attn_variant(int dtype, int D, int* dp, int* qf);
 /* GroupNorm statistics -> per-(batch,channel) scale/shift (fp32).  partial_ws: >= B*nchunk*2*C floats where
  * nchunk = ffn_gn_nchunk(HW).  Replaces torch GroupNorm inside diffusers blocks (attention.py:105-214). */
 int ffn_gn_nchunk(int HW);
+/* 1 if ffn_groupnorm handles this problem in one fused launch (no workspace needed), 0 if it needs the partial / scale / shift workspace */
+int ffn_gn_fused(int B, int HW, int C, int G);
 int ffn_gn_stats(void* stream, int dtype, const void* x, const float* gamma, const float* beta, int B, int HW, int C, int G,
                  float eps, float* partial_ws, float* scale, float* shift);
 int ffn_gn_apply(void* stream, int dtype, const void* x, void* y, const float* scale, const float* shift, int B, int HW,
