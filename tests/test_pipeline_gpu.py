@@ -100,7 +100,7 @@ def test_image_batched_edits_match_single_edits(gpu, graph):
                                         draw_mask=c["draw_mask"], seed=sd, return_intermediates=True, **kw)
         single.append((img, [t.clone() for t in model.last_intermediates]))
     assert traj_dev(single[0][1], g[f"{name}_traj"]) < TOL
-    for sel in ([0, 1], [0, 1, 2]):
+    for sel in ([0, 1], [0, 1, 2], [1]):
         for rep in range(2 if graph else 1):                       # second pass replays the captured batched graphs
             imgs = model.FreeFine_generation_batch([cases[i] for i in sel], 7.5, 1.0, seeds=[seeds[i] for i in sel],
                                                    return_intermediates=True, **kw)
@@ -109,8 +109,8 @@ def test_image_batched_edits_match_single_edits(gpu, graph):
                 print(f"batch {sel} graph={graph} rep={rep} image {i}: latent L-inf vs single-image edit {dev:.2e}")
                 assert dev < 1e-4, (sel, i)
                 assert np.abs(imgs[j].astype(int) - single[i][0].astype(int)).max() <= 1
-            dev = traj_dev(model.last_intermediates[0], g[f"{name}_traj"])
-            assert dev < TOL
+            if sel[0] == 0:
+                assert traj_dev(model.last_intermediates[0], g[f"{name}_traj"]) < TOL
     # the single-image path is intact after batching (controller restored)
     c = cases[1]
     img = model.FreeFine_generation(c["ori_img"], c["ori_mask"], c["coarse_input"], c["target_mask"], c["guidance_text"], 7.5, 1.0,
