@@ -180,10 +180,12 @@ def blend_with_original(ori_img, hole_mask, generated):
     return (ori_img * (1 - mask_np) + generated * mask_np).astype(generated.dtype)
 
 
-def run_bggen(model, dst_base, blending=True, params=None, rank=0, world=1, check_exist=True, verbose=True, dsize=(512, 512), seed=None):
+def run_bggen(model, dst_base, blending=True, params=None, rank=0, world=1, check_exist=True, verbose=True, dsize=(512, 512), seed=None,
+              batch=4):
     """remove the annotated object of every (image, instance) with FreeFine_background_generation (model must carry the bg-gen hook:
-    register_attention_control_4bggen).  seed=None draws a fresh seed per case like the reference (:162)."""
+    register_attention_control_4bggen), `batch` cases per UNet batch.  seed=None draws a fresh seed per case like the reference (:162)."""
     import random
+    from PIL import Image
     from src.utils.vis_utils import read_and_resize_mask_with_dilation
     from . import dist as FD
     params = dict(GEOBENCH_BGGEN, **(params or {}))
@@ -193,22 +195,29 @@ def run_bggen(model, dst_base, blending=True, params=None, rank=0, world=1, chec
     if data is None:
         raise FileNotFoundError(osp.join(dst_base, "annotations_2d.json"))
     cl = InpaintCaseList(data, out_dir, check_exist)
+    mine = [cl[i] for i in FD.shard_indices(len(cl), rank, world)]
     done = []
-    for i in FD.shard_indices(len(cl), rank, world):
-        c = cl[i]
-        ori_img = read_and_resize_img(c["ori_img_path"], dsize)
-        hole = read_and_resize_mask_with_dilation(c["ori_mask_path"], dsize, dilation_factor=30, forbit_area=None)
-        s = random.randint(0, 10 ** 16) if seed is None else seed
-        gen = model.FreeFine_background_generation(ori_img, hole, params["guidance_text"], params["guidance_scale"], params["eta"],
-                                                   end_step=params["end_step"], num_step=params["num_step"], start_step=params["start_step"],
-                                                   end_scale=params["end_scale"], seed=s % (2 ** 63), verbose=False)
-        if blending:
-            gen = blend_with_original(ori_img, hole, gen)
-        d = osp.join(out_dir, str(c["da_n"]), str(c["ins_id"]))
-        os.makedirs(d, exist_ok=True)
-        from PIL import Image
-        Image.fromarray(gen).save(osp.join(d, "inp_img.png"))
-        done.append(dict(key=f'{c["da_n"]}/{c["ins_id"]}', da_n=c["da_n"], ins_id=c["ins_id"], inp_img_path=osp.join(d, "inp_img.png")))
+    kw = dict(end_step=params["end_step"], num_step=params["num_step"], start_step=params["start_step"], end_scale=params["end_scale"],
+              verbose=False)
+    for b0 in range(0, len(mine), batch):
+        group = mine[b0:b0 + batch]
+        imgs = [read_and_resize_img(c["ori_img_path"], dsize) for c in group]
+        holes = [read_and_resize_mask_with_dilation(c["ori_mask_path"], dsize, dilation_factor=30, forbit_area=None) for c in group]
+        seeds = [(random.randint(0, 10 ** 16) if seed is None else seed) % (2 ** 63) for _ in group]
+        if len(group) == 1:
+            gens = [model.FreeFine_background_generation(imgs[0], holes[0], params["guidance_text"], params["guidance_scale"], params["eta"],
+                                                         seed=seeds[0], **kw)]
+        else:
+            gens = model.FreeFine_background_generation_batch(
+                [dict(ori_img=im, ori_mask=h, guidance_text=params["guidance_text"]) for im, h in zip(imgs, holes)],
+                params["guidance_scale"], params["eta"], seeds=seeds, **kw)
+        for c, im, h, gen in zip(group, imgs, holes, gens):
+            if blending:
+                gen = blend_with_original(im, h, gen)
+            d = osp.join(out_dir, str(c["da_n"]), str(c["ins_id"]))
+            os.makedirs(d, exist_ok=True)
+            Image.fromarray(gen).save(osp.join(d, "inp_img.png"))
+            done.append(dict(key=f'{c["da_n"]}/{c["ins_id"]}', da_n=c["da_n"], ins_id=c["ins_id"], inp_img_path=osp.join(d, "inp_img.png")))
     merged = FD.gather_results(done) if world > 1 else done
     if verbose and rank == 0:
         print(f"background images generated: {len(merged)} (+{len(cl.existing_results)} existing)")

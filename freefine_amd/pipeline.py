@@ -804,6 +804,91 @@ class FreeFinePipeline:
         return [(to_u8(images[2 * k]), to_u8(images[2 * k + 1])) if return_ori else to_u8(images[2 * k]) for k in range(K)]
 
 
+    @torch.no_grad()
+    def FreeFine_background_generation_batch(self, cases, guidance_scale, eta, end_step=10, num_step=50, start_step=25, share_attn=True,
+                                             method_type="tca", local_text_edit=True, local_perturbation=True, verbose=True, seeds=42,
+                                             return_intermediates=False, end_scale=0.5):
+        """K independent FreeFine_background_generation calls (model.py:1088-1118 each) as one image-major batch: inversion runs K
+        rows, guided sampling K*Bp rows (rows of image i: generated stream, re-noised reference stream).  Needs the bg-gen hook
+        (register_attention_control_4bggen).  cases: dicts with ori_img, ori_mask, guidance_text.  Returns a list of images."""
+        assert method_type in self._METHODS and guidance_scale > 1.0
+        assert self.unet.hook == "bggen", "register_attention_control_4bggen(model, controller) first"
+        K = len(cases)
+        seeds = [seeds] * K if isinstance(seeds, int) else list(seeds)
+        single = self.controller
+        ctrls = self._controllers_for_batch(K)
+        self.unet.controller = ctrls if K > 1 else single
+        try:
+            seed_everything(seeds[0])
+            gens = [torch.Generator().manual_seed(sd) for sd in seeds]
+            red = self.mask_reduce_dim
+            source = torch.from_numpy(np.stack([c["ori_img"] for c in cases]))
+            for c in ctrls:
+                c.reset()
+            _, inverted = self.invert(source, "", guidance_scale=1.0, num_inference_steps=num_step,
+                                      num_actual_inference_steps=num_step - start_step, return_intermediates=True)
+            for c in ctrls:
+                c.reset()
+            init, refer = inverted[-1], inverted[::-1]
+            cfg_f, var_masks, texts = [], [], []
+            for case, c in zip(cases, ctrls):
+                full_h, full_w = case["ori_img"].shape[:2]
+                mask_t, var_m = self.prepare_mask_bggen(red(case["ori_mask"]), full_h, full_w, init)
+                c.fg_retain_mask, c.local_edit_region = mask_t, mask_t
+                c.reset()
+                self.controller = c
+                self._configure_method(method_type, share_attn)
+                c.local_edit = local_text_edit
+                cfg_f.append(self._mask_f(var_m) if local_text_edit else None)
+                var_masks.append(var_m if local_perturbation else torch.ones_like(var_m))
+                texts.append(torch.cat([self._encode_text(["", ""]), self._encode_text([case["guidance_text"], ""])], dim=0))
+            self.controller = ctrls[0]
+            maps = [self._cfg_row_map(t, 2) for t in texts]
+            if all(m[0] is not None and m[0] == maps[0][0] for m in maps):
+                row_map, lat_rows, txt_rows = maps[0]
+            else:
+                row_map, lat_rows, txt_rows = None, [0, 1, 0, 1], [0, 1, 2, 3]
+            text_phys = torch.cat([t[txt_rows] for t in texts], dim=0).contiguous()
+            lat_idx = torch.tensor([2 * i + r for i in range(K) for r in lat_rows], device=self.device)
+            self.scheduler.set_timesteps(num_step)
+            shape1 = tuple(init.shape[1:])
+            noises = []
+            for g in gens:
+                self._gen = g
+                noises.append(self._predraw_noise(num_step - start_step, (2,) + shape1, eta))
+            latents = torch.zeros((2 * K,) + shape1, dtype=init.dtype, device=init.device)     # rows (generated_i, reference_i)
+            lat_v = latents.view(K, 2, *shape1)
+            lat_v[:, 0] = init
+            inter = [[init[k:k + 1]] for k in range(K)] if return_intermediates else None
+            for i, t in enumerate(self.scheduler.timesteps):
+                if i < start_step:
+                    continue
+                lat_v[:, 1] = refer[i - start_step]                     # aligned reference latent (model.py:756)
+                for c in ctrls:
+                    if method_type == "tca":
+                        c.context_guidance = self.linear_param(i, start_step, end_step, num_step, end_scale=end_scale)
+                    elif method_type == "mmsa_es" and i >= end_step:
+                        c.use_tca = False
+                eps = self.unet(latents.index_select(0, lat_idx), t, encoder_hidden_states=text_phys, row_map=row_map)
+                eps = eps.view(K, 4, *shape1)
+                new = torch.empty_like(latents)
+                for k in range(K):
+                    e = ops.cfg_masked(eps[k, :2].contiguous(), eps[k, 2:].contiguous(), cfg_f[k], guidance_scale)
+                    new[2 * k:2 * k + 2] = self.ctrl_step(e, t, latents[2 * k:2 * k + 2], var_masks[k], eta=eta,
+                                                          noise=None if noises[k] is None else noises[k][i - start_step])[0]
+                    if inter is not None:
+                        inter[k].append(new[2 * k])
+                latents = new
+                lat_v = latents.view(K, 2, *shape1)
+            for c in ctrls:
+                c.reset()
+            images = self.latent2image(latents, return_type="pt")
+            self.last_intermediates = inter
+            return [(images[2 * k].permute(1, 2, 0).detach().cpu().numpy() * 255).astype(np.uint8) for k in range(K)]
+        finally:
+            self.controller = single
+            self.unet.controller = single
+
     def FreeFine_background_generation(self, ori_img, ori_mask, guidance_text, guidance_scale, eta, end_step=10, num_step=50,
                                        start_step=25, share_attn=True, method_type="tca", local_text_edit=True, local_perturbation=True,
                                        verbose=True, seed=42, return_intermediates=False, end_scale=0.5, latent_blended=False,

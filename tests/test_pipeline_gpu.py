@@ -203,3 +203,30 @@ def test_geobench_harness_on_gpu(gpu, tmp_path):
     saved = np.asarray(Image.open(case["gen_img_path"]))
     assert saved.shape == (128, 128, 3) and np.isfinite(direct.astype(float)).all()
     assert np.abs(saved.astype(int) - direct.astype(int)).max() <= 1
+
+
+def test_image_batched_background_generation_matches_single(gpu):
+    """FreeFine_background_generation_batch == the single-image calls (and image 0 of the golden bg_tca configuration still
+    matches the REFERENCE's golden trajectory)."""
+    g = np.load(os.path.join(GOLD, "g5_loops.npz"))
+    ori_img, coarse, img2 = synth_images()
+    ori, tgt, *_ = mask_inputs()
+    name, kw = BG_CASES[0]
+    model = make_pipe(gpu, "tiny", "bggen", graph=True)
+    holes = [model.dilate_mask(ori // 255, 30), model.dilate_mask(tgt // 255, 12)]
+    imgs_in, texts, seeds = [ori_img, img2], ["empty scene", "a quiet street"], [7, 99]
+    single = []
+    for im, hole, txt, sd in zip(imgs_in, holes, texts, seeds):
+        out = model.FreeFine_background_generation(im, hole, txt, 3.5, 1.0, verbose=True, seed=sd, return_intermediates=True, **kw)
+        single.append((out, [t.clone() for t in model.last_intermediates]))
+    assert traj_dev(single[0][1], g[f"{name}_traj"]) < TOL
+    cases = [dict(ori_img=im, ori_mask=hole, guidance_text=txt) for im, hole, txt in zip(imgs_in, holes, texts)]
+    for rep in range(2):
+        outs = model.FreeFine_background_generation_batch(cases, 3.5, 1.0, seeds=seeds, return_intermediates=True, **kw)
+        for k in range(2):
+            dev = traj_dev(model.last_intermediates[k], [t.cpu().numpy() for t in single[k][1]])
+            print(f"bg batch rep={rep} image {k}: latent L-inf vs single-image call {dev:.2e}")
+            assert dev < 1e-4
+            assert np.abs(outs[k].astype(int) - single[k][0].astype(int)).max() <= 1
+    out = model.FreeFine_background_generation(imgs_in[1], holes[1], texts[1], 3.5, 1.0, verbose=True, seed=seeds[1], return_intermediates=True, **kw)
+    assert traj_dev(model.last_intermediates, [t.cpu().numpy() for t in single[1][1]]) < 1e-5
