@@ -243,7 +243,7 @@ extern "C" int ffn_attn_variant(int dtype, int D, int* dp, int* qf) {
 enum { CFG_64x64, CFG_128x64, CFG_128x128_8, CFG_128x128_16, CFG_256x128, CFG_256x256, CFG_128x320, CFG_128x160, CFG_192x320, CFG_H_128x320, CFG_H_256x128, CFG_H_256x256, CFG_H_128x128, CFG_COUNT };
 struct IgCfgInfo { int bm, bn, nwm, nwn; };
 static const IgCfgInfo kCfg[CFG_COUNT] = {{64, 64, 2, 2}, {128, 64, 4, 2}, {128, 128, 2, 4}, {128, 128, 4, 4},
-                                          {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 320, 4, 4}, {128, 160, 4, 2}, {192, 320, 4, 4},
+                                          {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 320, 4, 4}, {128, 160, 4, 2}, {192, 320, 3, 4},
                                           {128, 320, 4, 4}, {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 128, 4, 4}};   // last four: halo kernel (3x3 stride-1 convs)
 struct IgChoice { int cfg, splitk; };
 
@@ -288,7 +288,7 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
         FFN_CFG_CASE(CFG_256x256, 256, 256, 4, 4)
         FFN_CFG_CASE(CFG_128x320, 128, 320, 4, 4)
         FFN_CFG_CASE(CFG_128x160, 128, 160, 4, 2)
-        FFN_CFG_CASE(CFG_192x320, 192, 320, 4, 4)
+        FFN_CFG_CASE(CFG_192x320, 192, 320, 3, 4)      // 12 waves: 168 registers per wave (spills at 16 waves x 128)
         case CFG_H_128x320:
         case CFG_H_256x128:
         case CFG_H_256x256:
