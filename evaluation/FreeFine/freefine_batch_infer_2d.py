@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--model", default="synthetic:sd21-base")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="f32 = parity mode (the reference runs fp32 here), bf16 = fast mode")
     ap.add_argument("--batch", type=int, default=4, help="cases edited together in one UNet batch")
+    ap.add_argument("--variant", default="2d", choices=["2d", "3d_depth"])
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank, local = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
@@ -43,7 +44,7 @@ def main():
     model.enable_xformers_memory_efficient_attention()
     model.unet.use_graph = True
     from freefine_amd import geobench
-    geobench.run(model, args.base_dir, batch=args.batch, rank=rank, world=world)
+    geobench.run(model, args.base_dir, batch=args.batch, rank=rank, world=world, variant=args.variant)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -22,6 +22,14 @@ from src.utils.vis_utils import load_json, re_edit_2d, read_and_resize_img, read
 GEOBENCH_2D = dict(guidance_scale=7.5, eta=1.0, end_scale=0.0, end_step=50, num_step=50, start_step=35, seed=42)
 GEN_SUBDIR = "Geo-Bench-2D/Gen_results_FreeFine_2d"
 INP_SUBDIR = "Geo-Bench-2D/inp_img_blended"
+# the GeoBench-3D (depth-guided coarse edit) call parameters (freefine_batch_infer_3d_depth.py:144-162): the coarse input was
+# rendered beforehand by the 3-D front end (DepthAnything + point-cloud warp, out of scope here) and is read from disk
+GEOBENCH_3D_DEPTH = dict(guidance_scale=7.5, eta=1.0, end_scale=0.0, end_step=50, num_step=50, start_step=15, seed=42)
+VARIANTS = {
+    "2d": dict(params=GEOBENCH_2D, annotations="annotations_2d.json", gen_subdir=GEN_SUBDIR, results="generated_results_freefine_2d.json"),
+    "3d_depth": dict(params=GEOBENCH_3D_DEPTH, annotations="annotations.json", gen_subdir="Geo-Bench-3D/Gen_results_FreeFine_depth",
+                     results="generated_results_freefine_depth.json"),
+}
 
 
 class CaseList:
@@ -62,13 +70,22 @@ def load_case(case, dst_base, dsize=(512, 512)):
                 draw_mask=np.ones_like(ori_mask), use_auto_draw=True, reduce_inp_artifacts=True, cons_area=target_mask)
 
 
-def _prefetch(cases, dst_base, depth, dsize):
+def load_case_3d_depth(case, dst_base, dsize=(512, 512)):
+    """host pre-processing of one GeoBench-3D case (freefine_batch_infer_3d_depth.py:127-143)"""
+    coarse = read_and_resize_img(osp.join(dst_base, "coarse3d_depth_anything", str(case["da_n"]), str(case["ins_id"]), f'{case["edit_ins"]}.png'), dsize)
+    target_mask = read_and_resize_mask(case["target_mask_0"], dsize)
+    return dict(ori_img=read_and_resize_img(case["ori_img_path"], dsize), ori_mask=read_and_resize_mask(case["ori_mask_path"], dsize),
+                coarse_input=coarse, target_mask=target_mask, guidance_text=case["obj_label"],
+                draw_mask=read_and_resize_mask(case["draw_mask"], dsize), use_auto_draw=False, reduce_inp_artifacts=True, cons_area=target_mask)
+
+
+def _prefetch(cases, dst_base, depth, dsize, loader=None):
     q = queue.Queue(maxsize=depth)
 
     def work():
         for c in cases:
             try:
-                q.put((c, load_case(c, dst_base, dsize), None))
+                q.put((c, (loader or load_case)(c, dst_base, dsize), None))
             except Exception as e:  # noqa: BLE001 -- reported on the consumer side with the case attached
                 q.put((c, None, e))
         q.put(None)
@@ -81,17 +98,19 @@ def _prefetch(cases, dst_base, depth, dsize):
         yield item
 
 
-def run(model, dst_base, batch=4, params=None, rank=0, world=1, check_exist=True, verbose=True, dsize=(512, 512)):
-    """edit every case of <dst_base>/annotations_2d.json that this rank owns; rank 0 writes generated_results_freefine_2d.json.
+def run(model, dst_base, batch=4, params=None, rank=0, world=1, check_exist=True, verbose=True, dsize=(512, 512), variant="2d"):
+    """edit every case of the variant's annotation file that this rank owns; rank 0 writes the variant's result JSON
+    (2d: annotations_2d.json -> generated_results_freefine_2d.json; 3d_depth: annotations.json -> generated_results_freefine_depth.json).
     Returns the merged result list (on every rank)."""
     from . import dist as FD
-    params = dict(GEOBENCH_2D, **(params or {}))
+    V = VARIANTS[variant]
+    params = dict(V["params"], **(params or {}))
     seed = params.pop("seed")
-    dst_gen = osp.join(dst_base, GEN_SUBDIR)
+    dst_gen = osp.join(dst_base, V["gen_subdir"])
     os.makedirs(dst_gen, exist_ok=True)
-    data = load_json(osp.join(dst_base, "annotations_2d.json"))
+    data = load_json(osp.join(dst_base, V["annotations"]))
     if data is None:
-        raise FileNotFoundError(osp.join(dst_base, "annotations_2d.json"))
+        raise FileNotFoundError(osp.join(dst_base, V["annotations"]))
     cl = CaseList(data, dst_gen, check_exist)
     mine = [cl[i] for i in FD.shard_indices(len(cl), rank, world)]
     results = []
@@ -117,7 +136,7 @@ def run(model, dst_base, batch=4, params=None, rank=0, world=1, check_exist=True
             results.append(dict(c, gen_img_path=path, key=f'{c["da_n"]}/{c["ins_id"]}/{c["edit_ins"]}'))
         pending.clear()
 
-    for case, inputs, err in _prefetch(mine, dst_base, 2 * batch, dsize):
+    for case, inputs, err in _prefetch(mine, dst_base, 2 * batch, dsize, load_case_3d_depth if variant == "3d_depth" else load_case):
         if err is not None:
             if verbose:
                 print(f'[geobench] skipped {case["da_n"]}/{case["ins_id"]}/{case["edit_ins"]}: {err}')
@@ -133,7 +152,7 @@ def run(model, dst_base, batch=4, params=None, rank=0, world=1, check_exist=True
         for it in final:
             it = {k: v for k, v in it.items() if k != "key"}
             new_data.setdefault(it["da_n"], {"instances": {}})["instances"].setdefault(it["ins_id"], {})[it["edit_ins"]] = it
-        save_json(new_data, osp.join(dst_base, "generated_results_freefine_2d.json"))
+        save_json(new_data, osp.join(dst_base, V["results"]))
         if verbose:
             print(f"Total images processed: {len(final)}")
     return merged
@@ -224,7 +243,7 @@ def run_bggen(model, dst_base, blending=True, params=None, rank=0, world=1, chec
     return merged
 
 
-def make_synthetic_dataset(root, n_images=2, edits_per_image=2, size=96, seed=0, with_backgrounds=True):
+def make_synthetic_dataset(root, n_images=2, edits_per_image=2, size=96, seed=0, with_backgrounds=True, with_3d=False):
     """a GeoBenchMeta-shaped tree with seeded random images / rectangular instance masks / affine edit parameters (no dataset
     exists offline): annotations_2d.json, source PNGs, Geo-Bench-2D/inp_img_blended/<da>/<ins>/inp_img.png."""
     from PIL import Image
@@ -250,6 +269,25 @@ def make_synthetic_dataset(root, n_images=2, edits_per_image=2, size=96, seed=0,
             dx, dy = int(rng.integers(4, size // 4)), int(rng.integers(-4, size // 6))
             edits[str(e)] = dict(ori_img_path=ip, ori_mask_path=mp, edit_param=[dx, dy, 0, 0, 0, float(rng.integers(-20, 20)), 1.0, 1.0, 1.0],
                                  edit_prompt="move")
+            if with_3d:      # the GeoBench-3D annotation fields + the pre-rendered coarse edit (here: the same object shifted)
+                tmask = np.roll(mask, (dy, dx), axis=(0, 1))
+                draw = np.clip(ndimage_max(tmask, 9), 0, 255)
+                tp = osp.join(root, "source", da, f"tgt_{e}.png")
+                dp = osp.join(root, "source", da, f"draw_{e}.png")
+                Image.fromarray(tmask).save(tp)
+                Image.fromarray(draw).save(dp)
+                cdir = osp.join(root, "coarse3d_depth_anything", da, "0")
+                os.makedirs(cdir, exist_ok=True)
+                coarse = np.where(tmask[:, :, None] > 0, np.roll(img, (dy, dx), axis=(0, 1)), img)
+                Image.fromarray(coarse).save(osp.join(cdir, f"{e}.png"))
+                edits[str(e)].update(target_mask_0=tp, draw_mask=dp, obj_label="a cup")
         data[da] = {"instances": {"0": edits}}
     save_json(data, osp.join(root, "annotations_2d.json"))
+    if with_3d:
+        save_json(data, osp.join(root, "annotations.json"))
     return data
+
+
+def ndimage_max(mask, k):
+    from scipy import ndimage
+    return ndimage.maximum_filter(mask, size=(k, k), mode="constant", cval=0)

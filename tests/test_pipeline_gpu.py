@@ -203,6 +203,13 @@ def test_geobench_harness_on_gpu(gpu, tmp_path):
     saved = np.asarray(Image.open(case["gen_img_path"]))
     assert saved.shape == (128, 128, 3) and np.isfinite(direct.astype(float)).all()
     assert np.abs(saved.astype(int) - direct.astype(int)).max() <= 1
+    # GeoBench-3D variant: coarse edits / target / draw masks read from disk, text = object label, start_step 15
+    root3 = str(tmp_path / "geo3d")
+    geobench.make_synthetic_dataset(root3, n_images=1, edits_per_image=3, size=128, seed=5, with_3d=True)
+    res3 = geobench.run(model, root3, batch=2, params=dict(num_step=10, start_step=3, end_step=10), dsize=(128, 128), verbose=False,
+                        variant="3d_depth")
+    assert len(res3) == 3 and os.path.exists(os.path.join(root3, "generated_results_freefine_depth.json"))
+    assert all(np.asarray(Image.open(r["gen_img_path"])).shape == (128, 128, 3) for r in res3)
 
 
 def test_image_batched_background_generation_matches_single(gpu):
