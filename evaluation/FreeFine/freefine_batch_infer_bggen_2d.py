@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--model", default="synthetic:sd21-base")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--no-blending", action="store_true")
+    ap.add_argument("--bench", default="2D", choices=["2D", "3D"])
     ap.add_argument("--batch", type=int, default=4, help="cases processed together in one UNet batch")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -37,7 +38,7 @@ def main():
     model.modify_unet_forward()
     model.unet.use_graph = True
     from freefine_amd import geobench
-    geobench.run_bggen(model, args.base_dir, blending=not args.no_blending, rank=rank, world=world, batch=args.batch)
+    geobench.run_bggen(model, args.base_dir, blending=not args.no_blending, rank=rank, world=world, batch=args.batch, bench=args.bench)
     if world > 1:
         torch.distributed.destroy_process_group()
 

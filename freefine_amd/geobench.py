@@ -200,7 +200,7 @@ def blend_with_original(ori_img, hole_mask, generated):
 
 
 def run_bggen(model, dst_base, blending=True, params=None, rank=0, world=1, check_exist=True, verbose=True, dsize=(512, 512), seed=None,
-              batch=4):
+              batch=4, bench="2D"):
     """remove the annotated object of every (image, instance) with FreeFine_background_generation (model must carry the bg-gen hook:
     register_attention_control_4bggen), `batch` cases per UNet batch.  seed=None draws a fresh seed per case like the reference (:162)."""
     import random
@@ -208,11 +208,13 @@ def run_bggen(model, dst_base, blending=True, params=None, rank=0, world=1, chec
     from src.utils.vis_utils import read_and_resize_mask_with_dilation
     from . import dist as FD
     params = dict(GEOBENCH_BGGEN, **(params or {}))
-    out_dir = osp.join(dst_base, INP_SUBDIR if blending else "Geo-Bench-2D/inp_img_no_blend")
+    # bench = "2D" | "3D": annotations_2d.json -> Geo-Bench-2D/..., annotations_3d.json -> Geo-Bench-3D/... (freefine_batch_infer_bggen_3d.py)
+    ann = f"annotations_{bench.lower()}.json"
+    out_dir = osp.join(dst_base, f"Geo-Bench-{bench}", "inp_img_blended" if blending else "inp_img_no_blend")
     os.makedirs(out_dir, exist_ok=True)
-    data = load_json(osp.join(dst_base, "annotations_2d.json"))
+    data = load_json(osp.join(dst_base, ann))
     if data is None:
-        raise FileNotFoundError(osp.join(dst_base, "annotations_2d.json"))
+        raise FileNotFoundError(osp.join(dst_base, ann))
     cl = InpaintCaseList(data, out_dir, check_exist)
     mine = [cl[i] for i in FD.shard_indices(len(cl), rank, world)]
     done = []
