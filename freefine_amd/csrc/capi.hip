@@ -441,12 +441,17 @@ static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
     for (int i = 0; i < nc; ++i) {
         int rc = launch_bf16_cfg<AMODE>(s, d, cand[i]);      // warm (LDS opt-in, code load)
         if (rc) continue;
-        (void)hipEventRecord(e0, s);
-        for (int r = 0; r < reps && !rc; ++r) rc = launch_bf16_cfg<AMODE>(s, d, cand[i]);
-        (void)hipEventRecord(e1, s);
-        if (rc || hipEventSynchronize(e1) != hipSuccess) continue;
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
+        float ms = 1e30f;
+        for (int round = 0; round < 2 && !rc; ++round) {       // min of two timed groups: one noisy group must not pick the configuration
+            (void)hipEventRecord(e0, s);
+            for (int r = 0; r < reps && !rc; ++r) rc = launch_bf16_cfg<AMODE>(s, d, cand[i]);
+            (void)hipEventRecord(e1, s);
+            if (rc || hipEventSynchronize(e1) != hipSuccess) { rc = rc ? rc : FFN_EHIP; break; }
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, e0, e1);
+            if (t < ms) ms = t;
+        }
+        if (rc) continue;
         if (ms < best_ms) { best_ms = ms; best = cand[i]; }
     }
     (void)hipEventDestroy(e0);
