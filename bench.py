@@ -266,6 +266,7 @@ def main():
                        "images_per_gpu_per_step": args.concurrent * args.batch, "concurrent_streams": args.concurrent,
                        "images_per_unet_batch": args.batch, "unet_batch": 4 * args.batch, "hip_graph": not args.no_graph,
                        "exact_row_dedup": model.dedup_rows and "on: the duplicated reference row of the CFG batch is evaluated once (3 physical rows), outputs unchanged",
+                       "vae_decode": "batched path decodes the edited latent only (the reference decodes the reference stream too and drops it unless return_ori)" if args.batch > 1 else "both streams, like the reference",
                        "algorithmic_tflop_per_image": round(f_img / 1e12, 1),
                        "whole_path_tflops_per_gpu": round(f_img * value / world / 1e12, 1),
                        "whole_path_frac_of_mfma_peak": round(f_img * value / world / 1e12 / PEAK_TFLOPS[args.dtype], 4)},

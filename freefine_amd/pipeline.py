@@ -798,10 +798,15 @@ class FreeFinePipeline:
             lat_v = latents.view(K, 2, *init.shape[1:])
         for c in ctrls:
             c.reset()
-        images = self.latent2image(latents, return_type="pt")
         to_u8 = lambda im: (im.permute(1, 2, 0).detach().cpu().numpy() * 255).astype(np.uint8)
         self.last_intermediates = inter
-        return [(to_u8(images[2 * k]), to_u8(images[2 * k + 1])) if return_ori else to_u8(images[2 * k]) for k in range(K)]
+        if return_ori:
+            images = self.latent2image(latents, return_type="pt")
+            return [(to_u8(images[2 * k]), to_u8(images[2 * k + 1])) for k in range(K)]
+        # the reference decodes both streams and drops the reference image unless return_ori (model.py:619, 1046-1049): decode only
+        # the edited rows (VAE decode is per row: the kept image is unchanged)
+        images = self.latent2image(latents[0::2].contiguous(), return_type="pt")
+        return [to_u8(images[k]) for k in range(K)]
 
 
     @torch.no_grad()
@@ -882,9 +887,9 @@ class FreeFinePipeline:
                 lat_v = latents.view(K, 2, *shape1)
             for c in ctrls:
                 c.reset()
-            images = self.latent2image(latents, return_type="pt")
+            images = self.latent2image(latents[0::2].contiguous(), return_type="pt")      # only the generated rows are returned (model.py:1118)
             self.last_intermediates = inter
-            return [(images[2 * k].permute(1, 2, 0).detach().cpu().numpy() * 255).astype(np.uint8) for k in range(K)]
+            return [(images[k].permute(1, 2, 0).detach().cpu().numpy() * 255).astype(np.uint8) for k in range(K)]
         finally:
             self.controller = single
             self.unet.controller = single
