@@ -35,7 +35,10 @@
 #define ATT_MAXP FFN_ATT_MAXP
 #define ATT_MAXB FFN_ATT_MAXB
 enum { ATT_HEAD_RULE = FFN_ATT_HEAD_RULE, ATT_UNIFORM_SEL1 = FFN_ATT_UNIFORM_SEL1, ATT_UNIFORM_SEL0 = FFN_ATT_UNIFORM_SEL0 };
-typedef __attribute__((address_space(3))) u32x2 lds_u32x2_t;   // explicit LDS pointer type for the volatile V^T fragment reads
+typedef __attribute__((address_space(3))) u32x2 lds_u32x2_t;
+typedef __attribute__((address_space(1))) const void* att_gptr_t;
+typedef __attribute__((address_space(3))) void* att_lptr_t;
+__device__ __attribute__((aligned(16))) const uint32_t g_att_zero[4] = {0, 0, 0, 0};   // explicit LDS pointer type for the volatile V^T fragment reads
 typedef ffn_attn_entry AttnEntry;
 typedef ffn_attn_desc AttnParams;
 
@@ -67,7 +70,8 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
     constexpr int NT = KT / 16;                 // 16-key fragments per tile
     constexpr bool KSWZ = (DP * SZ == 128);     // 128-byte K rows: XOR-swizzled chunks (conflict-free ds_read_b128, like igemm)
     constexpr int KROW = KSWZ ? 128 : DP * SZ + 16;   // otherwise +16 B row padding (2-way conflicts on some lane groups)
-    constexpr int VROW = KT * SZ + 16;          // V^T tile row stride
+    constexpr bool GLDS = KSWZ && (KT * SZ == 128);    // bf16, d = 64: K and V^T tiles go global -> LDS directly (no register staging)
+    constexpr int VROW = GLDS ? 128 : KT * SZ + 16;   // V^T tile row stride (GLDS: unpadded 128-byte rows, chunks XOR-swizzled by (row>>1)&7)
     constexpr int DCH = DP / EPC;               // 16-byte chunks per K row
     constexpr int DSL = DP * SZ / 64;           // 64-byte d-slabs (MFMA k-substeps of QK^T)
     constexpr int FD = DP / 16;                 // d fragments of O^T
@@ -204,8 +208,34 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
         uint32_t rmk = 0;           // FAST: mask byte of key k0 + tid of the tile in flight (threads < KT)
         const T* kbase = Kg + (long)en.kv_row * p.Sk * p.ldk + head * D;
         const T* vbase = Vg + ((long)en.kv_row * p.heads * D + head * D) * p.ldvt;
+        // GLDS: wave-instruction q (2 per wave for K, 2 for V^T) covers tile rows 8q..8q+7; lane>>3 picks the row, lane&7 the chunk
+        // position, the lane fetches the source chunk position ^ swizzle(row); out-of-range rows / chunks come from the zero page
+        auto issue_glds = [&](int k0, int buf) {
+            if constexpr (GLDS) {
+                const char* zp = reinterpret_cast<const char*>(g_att_zero);
+                const int lr = lane >> 3, lp = lane & 7;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = 8 * (wave + 4 * i) + lr;               // key row of the K tile
+                    const int c = lp ^ (row & 7);
+                    const bool ok = k0 + row < p.Sk && c * EPC < D;
+                    const char* src = ok ? reinterpret_cast<const char*>(kbase + (long)(k0 + row) * p.ldk + c * EPC) : zp;
+                    __builtin_amdgcn_global_load_lds((att_gptr_t)src, (att_lptr_t)(Ks + buf * KBUF + (8 * (wave + 4 * i)) * 128), 16, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = 8 * (wave + 4 * i) + lr;               // d row of the V^T tile
+                    const int c = lp ^ ((row >> 1) & 7);
+                    const int kk = k0 + c * EPC;
+                    const bool ok = row < D && kk < p.Sk;                  // a chunk that starts inside Sk ends inside ldvt (multiple of 8, finite padding)
+                    const char* src = ok ? reinterpret_cast<const char*>(vbase + (long)row * p.ldvt + kk) : zp;
+                    __builtin_amdgcn_global_load_lds((att_gptr_t)src, (att_lptr_t)(Vs + buf * VBUF + (8 * (wave + 4 * i)) * 128), 16, 0, 0);
+                }
+            }
+        };
         auto issue = [&](int k0) {
             if (FAUG && pass_masked && tid < KT) rmk = (k0 + tid < p.Sk) ? en.kmask[k0 + tid] : 0;
+            if (GLDS) return;
 #pragma unroll
             for (int i = 0; i < NKC; ++i) {
                 const int cid = tid + 256 * i;
@@ -234,6 +264,10 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
         };
         auto stage = [&](int buf) {
             if (FAUG && pass_masked && tid < KT) Ms[buf * KT + tid] = (uint8_t)rmk;
+            if (GLDS) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tile requested by issue_glds has landed (this wave's share)
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < NKC; ++i) {
                 const int cid = tid + 256 * i;
@@ -347,12 +381,14 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
 #pragma unroll
                 for (int i = 0; i < FD; ++i) {
                     u32x4 va;
-                    const char* vrow = Vb + (i * 16 + l15) * VROW;
+                    const int vr = i * 16 + l15;
+                    const char* vrow = Vb + vr * VROW;
                     if (KPC == 1) {
                         va = *reinterpret_cast<const u32x4*>(vrow + (16 * c + 4 * g) * SZ);
                     } else {
-                        const u32x2 lo = *(const volatile lds_u32x2_t*)(vrow + (32 * c + 4 * g) * SZ);   // volatile: keep two ds_read_b64 (a merged ds_read2_b64 banks mod 32: 2-way conflicts, half rate)
-                        const u32x2 hi = *(const volatile lds_u32x2_t*)(vrow + (32 * c + 16 + 4 * g) * SZ);
+                        const int vsw = GLDS ? ((vr >> 1) & 7) : 0;
+                        const u32x2 lo = *(const volatile lds_u32x2_t*)(vrow + (((4 * c + (g >> 1)) ^ vsw) << 4) + 8 * (g & 1));
+                        const u32x2 hi = *(const volatile lds_u32x2_t*)(vrow + (((4 * c + 2 + (g >> 1)) ^ vsw) << 4) + 8 * (g & 1));
                         va = u32x4{lo[0], lo[1], hi[0], hi[1]};
                     }
 #pragma unroll
@@ -417,9 +453,12 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
             for (int c = 0; c < NT / KPC; ++c)
 #pragma unroll
                 for (int i = 0; i < FD; ++i) {
-                    const char* vrow = Vb + (i * 16 + l15) * VROW;
-                    const u32x2 lo = *(const volatile lds_u32x2_t*)(vrow + (32 * c + 4 * g) * SZ);   // volatile: keep two ds_read_b64 (a merged ds_read2_b64 banks mod 32: 2-way conflicts, half rate)
-                    const u32x2 hi = *(const volatile lds_u32x2_t*)(vrow + (32 * c + 16 + 4 * g) * SZ);
+                    const int vr = i * 16 + l15;
+                    const char* vrow = Vb + vr * VROW;
+                    // bytes 64c + 8g (keys 32c+4g..+3) and +32: chunk 4c + (g>>1) (+2), half g&1; GLDS rows are chunk-swizzled
+                    const int vsw = GLDS ? ((vr >> 1) & 7) : 0;
+                    const u32x2 lo = *(const volatile lds_u32x2_t*)(vrow + (((4 * c + (g >> 1)) ^ vsw) << 4) + 8 * (g & 1));   // volatile: keep two ds_read_b64 (a merged ds_read2_b64 banks mod 32: 2-way conflicts, half rate)
+                    const u32x2 hi = *(const volatile lds_u32x2_t*)(vrow + (((4 * c + 2 + (g >> 1)) ^ vsw) << 4) + 8 * (g & 1));
                     va[c][i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
                 }
             __builtin_amdgcn_sched_barrier(0);
@@ -471,11 +510,15 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
         };
 
         issue(0);
+        issue_glds(0, 0);
         stage(0);
         __syncthreads();
         for (int t = 0; t < ntiles; ++t) {
             const int k0 = t * KT, buf = t & 1;
-            if (t + 1 < ntiles) issue(k0 + KT);
+            if (t + 1 < ntiles) {
+                issue(k0 + KT);
+                issue_glds(k0 + KT, buf ^ 1);      // the other buffer was last read in tile t-1, before the barrier that ended it
+            }
             if constexpr (FAUG) {
                 if (any_uniform)                               // degenerate uniform-softmax queries in this wave: generic tile
                     tile(k0, buf, std::true_type{});

@@ -554,7 +554,8 @@ static int launch_attn(hipStream_t s, const ffn_attn_desc& d) {
     constexpr int SZ = sizeof(T);
     // double-buffered K and V^T tiles + the per-wave multi-pass accumulator
     constexpr int krow = (DP * SZ == 128) ? 128 : DP * SZ + 16;
-    constexpr int lds = 2 * (KT * krow + DP * (KT * SZ + 16)) + 4 * (DP / 16) * QF * 64 * 16 + 2 * KT;   // + key-mask bytes of the two staged tiles
+    constexpr int vrow = (DP * SZ == 128 && KT * SZ == 128) ? 128 : KT * SZ + 16;
+    constexpr int lds = 2 * (KT * krow + DP * vrow) + 4 * (DP / 16) * QF * 64 * 16 + 2 * KT;   // + key-mask bytes of the two staged tiles
     static_assert(lds <= 160 * 1024, "attention tile does not fit the 160 KiB LDS");
     auto kern = attn_kernel<T, DP, QF, KT, OCC, MASKS>;
     static bool lds_set = false;
