@@ -182,7 +182,7 @@ def main():
     ap.add_argument("--num-step", dest="num_step", type=int, default=50)
     ap.add_argument("--start-step", dest="start_step", type=int, default=0)
     ap.add_argument("--concurrent", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="independent edits per UNet batch (image-level batching)")
+    ap.add_argument("--batch", type=int, default=16, help="independent edits per UNet batch (image-level batching)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-dedup", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
