@@ -12,6 +12,7 @@
 #include "attention.h"
 #include "elementwise.h"
 #include "igemm.h"
+#include "igemm_p8.h"
 #include "norms.h"
 
 static thread_local char g_err[512] = "";
@@ -240,14 +241,35 @@ extern "C" int ffn_attn_variant(int dtype, int D, int* dp, int* qf) {
 // runs the N = 320 convs at 850-1000 TFLOP/s where 128x128 -- 17% of its third column tile wasted -- gives 690-760; 256x256
 // reaches 1190 on N = 1280 but loses 20% on N = 640).  So the first time a problem shape is seen outside stream capture, the
 // few plausible configurations are timed on the caller's stream with the caller's buffers and the winner is cached.
-enum { CFG_64x64, CFG_128x64, CFG_128x128_8, CFG_128x128_16, CFG_256x128, CFG_256x256, CFG_128x320, CFG_128x160, CFG_192x320, CFG_H_128x320, CFG_H_256x128, CFG_H_256x256, CFG_H_128x128, CFG_COUNT };
+enum { CFG_64x64, CFG_128x64, CFG_128x128_8, CFG_128x128_16, CFG_256x128, CFG_256x256, CFG_128x320, CFG_128x160, CFG_192x320, CFG_H_128x320, CFG_H_256x128, CFG_H_256x256, CFG_H_128x128, CFG_PP_256x320, CFG_PP_256x256, CFG_COUNT };
 struct IgCfgInfo { int bm, bn, nwm, nwn; };
 static const IgCfgInfo kCfg[CFG_COUNT] = {{64, 64, 2, 2}, {128, 64, 4, 2}, {128, 128, 2, 4}, {128, 128, 4, 4},
                                           {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 320, 4, 4}, {128, 160, 4, 2}, {192, 320, 3, 4},
-                                          {128, 320, 4, 4}, {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 128, 4, 4}};   // last four: halo kernel (3x3 stride-1 convs)
+                                          {128, 320, 4, 4}, {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 128, 4, 4},    // halo kernel (3x3 stride-1 convs)
+                                          {256, 320, 2, 4}, {256, 256, 2, 4}};                                         // ping-pong kernel (igemm_p8.h)
 struct IgChoice { int cfg, splitk; };
 
 static bool is_halo_cfg(int cfg) { return cfg == CFG_H_128x320 || cfg == CFG_H_256x128 || cfg == CFG_H_256x256 || cfg == CFG_H_128x128; }
+static bool is_pp_cfg(int cfg) { return cfg == CFG_PP_256x320 || cfg == CFG_PP_256x256; }
+// whether the ping-pong kernel (igemm_p8.h) handles this problem on a 256 x bn tile: its restrictions are listed in that header
+static bool pp_ok(const ffn_igemm_desc& d, int bn) {
+    const long lim = (1l << 31) - 4096;
+    if (d.K % 64 != 0 || d.K < 128 || d.N % bn != 0 || d.alpha != 1.0f || d.M < 256) return false;
+    if (d.flags & ~FFN_IG_GEGLU) return false;
+    if ((d.flags & FFN_IG_GEGLU) && bn != 256) return false;
+    if (d.rowbias && d.rows_per_batch % 128 != 0) return false;
+    long a_bytes;
+    if (d.conv) {
+        if (d.Cin % 64 != 0 || d.upsample || d.K != 9 * d.Cin || d.Cin / 64 * 9 * (d.Cin / 64) >= 65536) return false;
+        a_bytes = (long)(d.M / (d.Hout * d.Wout)) * d.Hin * d.Win * d.Cin * 2;
+        if (d.Hin + 2 >= 32768 || d.Win + 2 >= 32768) return false;
+    } else {
+        a_bytes = (long)d.M * d.lda * 2;
+    }
+    if (a_bytes + (256l * (d.conv ? d.Cin : d.lda) * 2) >= lim || (long)d.N * d.Kpad * 2 >= lim || (long)(d.M + 256) * d.ldo * 2 >= lim) return false;
+    if (d.residual && (long)(d.M + 256) * d.ldr * 2 >= lim) return false;
+    return true;
+}
 // LDS bytes of ONE halo buffer of the halo conv kernel for tile height bm, or 0 if the problem does not fit the kernel: 3x3,
 // stride 1, pad 1, no upsample, whole 64-channel chunks, and a tile = whole image rows (W <= bm) or a piece of one row
 static int halo_bytes_for(const ffn_igemm_desc& d, int bm) {
@@ -273,7 +295,9 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
     const int lds = 2 * (c.bm + c.bn) * 128, threads = 64 * c.nwm * c.nwn;
     int rc = FFN_OK;
     // FASTK kernels (streaming loader) need every 128-byte K stage inside K / inside one conv tap
-    const bool fastk = d.conv ? (d.Cin % 64 == 0 && d.Cin <= 30000) : (d.K % 64 == 0 && d.K <= 30000);   // 64 KiB zero page
+    // the streaming loader's zero-page pointers (N-tail columns, rows past M, conv padding) walk 128 B per K stage over the WHOLE K
+    // range of the launch: K * 2 bytes must stay inside the 64 KiB zero page
+    const bool fastk = (d.conv ? d.Cin % 64 == 0 : d.K % 64 == 0) && (long)d.K * 2 + 256 <= (long)sizeof(g_zero_page);
 #define FFN_CFG_CASE(ID, BM_, BN_, WM_, WN_)                                                                                               \
     case ID:                                                                                                                        \
         rc = fastk ? launch_igemm_kernel(igemm_glds_kernel<bf16, BM_, BN_, AMODE, true, 2, WM_, WN_, true>, lds, s, d, ntiles, ch.splitk, threads, true)  \
@@ -289,6 +313,35 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
         FFN_CFG_CASE(CFG_128x320, 128, 320, 4, 4)
         FFN_CFG_CASE(CFG_128x160, 128, 160, 4, 2)
         FFN_CFG_CASE(CFG_192x320, 192, 320, 3, 4)      // 12 waves: 168 registers per wave (spills at 16 waves x 128)
+        case CFG_PP_256x320:
+        case CFG_PP_256x256: {
+            if (!pp_ok(d, c.bn) || ch.splitk != 1) return fail(FFN_EINVAL, "igemm: ping-pong kernel not applicable");
+            const int pplds = 2 * (256 + c.bn) * 128 + 8192;
+            const int nt = ((d.M + 255) / 256) * (d.N / c.bn);
+            const int grid = nt < device_cus() ? nt : device_cus();
+            (void)hipGetLastError();
+#define FFN_PP_LAUNCH(BN_, RES_, GEGLU_)                                                   \
+    do {                                                                                   \
+        auto kern = igemm_pp_kernel<BN_, AMODE, RES_, GEGLU_>;                             \
+        if ((rc = set_lds(kern, pplds))) return rc;                                        \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pplds, s, d);                      \
+    } while (0)
+            if (ch.cfg == CFG_PP_256x320) {
+                if (d.residual) FFN_PP_LAUNCH(320, true, false);
+                else FFN_PP_LAUNCH(320, false, false);
+            } else {
+                if constexpr (AMODE == AMODE_DENSE) {
+                    if (d.flags & FFN_IG_GEGLU) FFN_PP_LAUNCH(256, false, true);
+                    else if (d.residual) FFN_PP_LAUNCH(256, true, false);
+                    else FFN_PP_LAUNCH(256, false, false);
+                } else {
+                    if (d.residual) FFN_PP_LAUNCH(256, true, false);
+                    else FFN_PP_LAUNCH(256, false, false);
+                }
+            }
+#undef FFN_PP_LAUNCH
+            return check_launch("igemm(ping-pong)");
+        }
         case CFG_H_128x320:
         case CFG_H_256x128:
         case CFG_H_256x256:
@@ -330,7 +383,7 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
 }
 
 struct TuneKey {
-    int M, N, K, conv, Cin, Hin, Win, stride, upsample, flags, lda, splitk, ptrs;
+    int M, N, K, conv, Cin, Hin, Win, stride, upsample, flags, lda, splitk, ptrs, wslabs, rpb, alpha1, ldo;
     bool operator==(const TuneKey& o) const { return memcmp(this, &o, sizeof(TuneKey)) == 0; }
 };
 struct TuneKeyHash {
@@ -347,6 +400,11 @@ static TuneKey tune_key(const ffn_igemm_desc& d) {
     k.M = d.M; k.N = d.N; k.K = d.K; k.conv = d.conv; k.flags = d.flags; k.lda = d.lda; k.splitk = d.splitk;
     if (d.conv) { k.Cin = d.Cin; k.Hin = d.Hin; k.Win = d.Win; k.stride = d.stride; k.upsample = d.upsample; }
     k.ptrs = (d.bias ? 1 : 0) | (d.rowbias ? 2 : 0) | (d.residual ? 4 : 0) | (d.ws && d.ws_bytes > 0 ? 8 : 0);
+    const long per = (long)d.M * d.N * 4;
+    k.wslabs = d.ws ? (int)(d.ws_bytes / per > 64 ? 64 : d.ws_bytes / per) : 0;      // how many split-K slabs the workspace holds
+    k.rpb = d.rows_per_batch;
+    k.alpha1 = d.alpha == 1.0f;
+    k.ldo = d.ldo;
     return k;
 }
 static std::mutex g_tune_mu;
@@ -379,14 +437,19 @@ static int candidates_for(const ffn_igemm_desc& d, IgChoice* out, int cap) {
             if (hb <= 0 || d.splitk > 1 || 2 * hb + 2 * c.bn * 128 > 160 * 1024) continue;
             if ((cfg == CFG_H_128x320) && (d.flags & FFN_IG_GEGLU)) continue;
         }
-        const bool halo = is_halo_cfg(cfg);
+        const bool halo = is_halo_cfg(cfg) || is_pp_cfg(cfg);                      // no split-K variants
+        if (is_pp_cfg(cfg) && (!pp_ok(d, c.bn) || d.splitk > 1)) continue;
         if (c.bm > 64 && c.bm >= 2 * d.M) continue;                                // tile mostly empty
         if (c.bn > 64 && c.bn >= 2 * d.N) continue;
         if (cfg == CFG_64x64 && (long)d.M * d.N > (1l << 22)) continue;
         const long tiles = (long)((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn);
         int splits[3] = {1, 0, 0};
-        if (d.splitk > 1) splits[0] = d.splitk;
-        else if (can_split(d) && !halo) {
+        if (d.splitk > 1) {              // caller-forced split: only where a split launch is legal and the workspace holds the slabs
+            int sf = (can_split(d) && !halo) ? d.splitk : 1;
+            if ((long)sf * per > d.ws_bytes) sf = (int)(d.ws_bytes / per);
+            if (sf > nk) sf = nk;
+            splits[0] = sf >= 2 ? sf : 1;
+        } else if (can_split(d) && !halo) {
             for (int t = 0; t < 2; ++t) {
                 int sgo = (int)(((t ? 512 : 256) + tiles / 2) / tiles);
                 if (sgo > nk / 4) sgo = nk / 4;
@@ -482,7 +545,12 @@ extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d, char* b
             snprintf(buf, len, "void igemm_halo_kernel<bf16, %d, %d, %d, %d>(ffn_igemm_desc, int)", c.bm, c.bn, c.nwm, c.nwn);
             return FFN_OK;
         }
-        const bool fastk = d->conv ? (d->Cin % 64 == 0 && d->Cin <= 30000) : (d->K % 64 == 0 && d->K <= 30000);
+        if (is_pp_cfg(ch.cfg)) {
+            snprintf(buf, len, "void igemm_pp_kernel<%d, %d, %s, %s>(ffn_igemm_desc)", c.bn, d->conv ? 1 : 0, d->residual ? "true" : "false",
+                     (d->flags & FFN_IG_GEGLU) ? "true" : "false");
+            return FFN_OK;
+        }
+        const bool fastk = (d->conv ? d->Cin % 64 == 0 : d->K % 64 == 0) && (long)d->K * 2 + 256 <= (long)sizeof(g_zero_page);
         snprintf(buf, len, "void igemm_glds_kernel<bf16, %d, %d, %d, true, 2, %d, %d, %s>(ffn_igemm_desc)", c.bm, c.bn, d->conv ? 1 : 0, c.nwm, c.nwn,
                  fastk ? "true" : "false");
         return FFN_OK;
@@ -548,6 +616,8 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
     return dtype == FFN_F32 ? dispatch_igemm<float>(s, *d) : dispatch_igemm<bf16>(s, *d);
 }
 
+extern "C" int ffn_igemm_tune(void* stream, int dtype, const ffn_igemm_desc* d) { return ffn_igemm(stream, dtype, d); }
+
 // ---- attention ---------------------------------------------------------------------------------------------------
 template <typename T, int DP, int QF, int KT = 64, int OCC = 1, bool MASKS = true>
 static int launch_attn(hipStream_t s, const ffn_attn_desc& d) {
@@ -558,12 +628,7 @@ static int launch_attn(hipStream_t s, const ffn_attn_desc& d) {
     constexpr int lds = 2 * (KT * krow + DP * vrow) + 4 * (DP / 16) * QF * 64 * 16 + 2 * KT;   // + key-mask bytes of the two staged tiles
     static_assert(lds <= 160 * 1024, "attention tile does not fit the 160 KiB LDS");
     auto kern = attn_kernel<T, DP, QF, KT, OCC, MASKS>;
-    static bool lds_set = false;
-    if (!lds_set) {
-        int rc = set_lds(kern, lds);
-        if (rc) return rc;
-        lds_set = true;
-    }
+    if (int rc = set_lds(kern, lds)) return rc;      // memoised under a mutex: safe from several host threads
     // 1-D grid, decoded in the kernel through xcd_remap: the query blocks of one (row, head) run on ONE XCD, whose 4 MiB L2 then
     // serves that head's K / V^T (1 MiB at S = 4096) to all of them (measured before: 721 MB fetched for 126 MB of operands)
     dim3 grid(((d.S + 64 * QF - 1) / (64 * QF)) * d.heads * d.Bo);
@@ -655,6 +720,7 @@ extern "C" int ffn_gn_stats(void* stream, int dtype, const void* x, const float*
         LAUNCH(gn_partial_kernel<float>, dim3(nchunk, B), dim3(256), lds, s, (const float*)x, partial_ws, HW, C, ppc);
     else
         LAUNCH(gn_partial_kernel<bf16>, dim3(nchunk, B), dim3(256), lds, s, (const bf16*)x, partial_ws, HW, C, ppc);
+    if (int rc = check_launch("gn_partial")) return rc;      // the next LAUNCH clears the error state: check before it
     LAUNCH(gn_finalize_kernel, dim3(G, B), dim3(64), 0, s, partial_ws, gamma, beta, scale, shift, HW, C, G, nchunk, eps);
     return check_launch("gn_stats");
 }

@@ -1,0 +1,364 @@
+// igemm_pp_kernel: the 256-row "ping-pong" member of the implicit-GEMM family (bf16 only, same operands as igemm.h).
+//
+// Why another structure.  The 2-stage kernels of igemm.h wait `vmcnt(0)` + barrier once per 64-deep K tile: every K tile starts with
+// an empty load pipe, and the two waves of a SIMD run their MFMA chains and their LDS reads in lockstep.  Measured (profiles/,
+// round 1): 39-46 % MFMA busy, ~50 % of wave cycles parked in s_waitcnt / s_barrier, the L2->LDS path idle between stages.  This
+// kernel is built the way cdna_hip_programming.md section 5 ("256^2 8-phase template", T3+T4+T5) describes:
+//   * 256 x BN output tile (BN = 256 or 320), 8 waves as 2 (M) x 4 (N), 128 x BN/4 outputs per wave (128 or 160 accumulator
+//     registers), one workgroup per CU, LDS = two whole K tiles (2 x (256 + BN) x 128 B = 128 / 144 KiB) + 8 KiB of column vectors;
+//   * a K tile (64 deep) is consumed in FOUR phases (k-substep 0: rows 0-63 of the wave, rows 64-127; k-substep 1: same), 16 or 20
+//     MFMAs each; the B fragments of a k-substep stay in registers for its two phases;
+//   * the next K tile's operands are requested in the SAME four phases (B, B, A rows {0-63,128-191}, A rows {64-127,192-255}: 2-3
+//     LDS-DMA loads per wave and phase) and stay in flight ACROSS the barriers: the only waits are two COUNTED
+//     `s_waitcnt vmcnt(N)` per K tile, never 0 in steady state;
+//   * waves 4-7 run the same program ONE BARRIER behind waves 0-3 (they share SIMDs pairwise): while one wave of a SIMD issues its
+//     MFMA chain (s_setprio 1) the other one reads fragments from LDS and issues the loads of its phase;
+//   * persistent over output tiles with the K-tile stream running straight across tile boundaries (the first K tile of the next
+//     output tile is requested while the last one of the current tile is multiplied);
+//   * NO global load in the epilogue: bias and the time-embedding row bias of the NEXT output tile arrive by LDS-DMA one K tile
+//     ahead (wave-private slots), the accumulators START at bias + row bias (+ residual, loaded once at the top of the tile), and
+//     the epilogue only converts and stores.  (In igemm_epilogue every fragment's bias / residual loads wait `vmcnt(0)` behind the
+//     previous fragment's stores -- the counter is in order --, which with 40 fragments per wave and two wave groups taking turns
+//     cost ~50 us per 256 x 320 tile: 154 us of a 385 us launch.)  Rounding: fl(bias + sum) instead of fl(fl(sum) + bias).
+//
+// LDS hazards (cdna_hip_programming.md section 5, "Read a staged buffer one phase AFTER the wait that retires it"):
+//   RAW  a counted wait placed at the END of the load section of phase q (before its first barrier) covers fragment reads from
+//        phase q+1 on, for both wave groups (the lagging group's wait precedes the same barrier event the leading group's reads
+//        follow).  Waits: end of phase 4 (B and A-low of the next K tile landed: read in phase 1), end of phase 1 (A-high landed:
+//        read in phase 2).
+//   WAR  a slot is re-staged >= 2 phases after the last phase that reads it: B is last read in phase 3 and re-staged in phases
+//        1-2 of the next K tile; A-low last read in phase 3, re-staged in phase 3; A-high last read in phase 4, re-staged in phase 4.
+//
+// Operand layout in LDS: rows of 128 B (64 bf16 of K), 16-byte chunks XOR-swizzled by (row & 7) through the SOURCE offset of the
+// direct-to-LDS loads (same image as igemm_glds_kernel): conflict-free ds_read_b128 fragment reads.
+//
+// Loads: BUFFER loads to LDS (`buffer_load_dwordx4 ... offen lds`).  The lane's 32-bit byte offset (voffset) says WHICH row / pixel
+// it fetches and changes only per output tile (dense A, W) or per conv tap; the position along K is a SCALAR offset (soffset)
+// stepped by 128 B per K tile -- no per-lane pointer arithmetic in the K loop.  Lanes whose offset lies outside the descriptor (rows
+// past M, and the zero padding of a convolution, encoded as offset 0x80000000) get ZEROS written to LDS by the range check (probed
+// on gfx950: tools/native/probe_bufload_lds.hip), so there is no zero page and no select.
+//
+// Restrictions (checked by the launcher, capi.hip): bf16; K % 64 == 0 and K >= 128 (conv: Cin % 64 == 0); N % BN == 0; alpha == 1;
+// flags subset of {GEGLU (BN = 256)}; no upsampling conv; rowbias only with rows_per_batch % 128 == 0; every operand < 2 GiB.
+#pragma once
+#include <type_traits>
+#include "igemm.h"
+
+#ifndef PP_ABL
+#define PP_ABL 0      // timing-only ablation builds of tools/native/pp_bench.hip: 1 = no global loads, 2 = no counted waits (results garbage)
+#endif
+template <int N>
+__device__ __forceinline__ void pp_wait_vmcnt() {
+    if (PP_ABL != 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pp_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int BN, int AMODE, bool RES, bool GEGLU>
+__global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
+    typedef bf16 T;
+    constexpr int BM = 256;
+    constexpr int FN = BN / 64;             // 16-column fragments per wave (4 or 5)
+    constexpr int WN = BN / 4;              // columns per wave
+    constexpr int ABYTES = BM * 128, BBYTES = BN * 128, BUF = ABYTES + BBYTES;
+    constexpr int CV = 2 * BUF;             // column vectors: per wave [bias | row bias] x 128 floats
+    constexpr int NB1 = (FN + 1) / 2;       // B pieces requested in phase 1 (the rest in phase 2)
+    constexpr int OOB = (int)0x80000000;
+    static_assert(BN == 256 || BN == 320, "tile widths built for this kernel");
+    static_assert(!GEGLU || FN % 2 == 0, "GEGLU pairs hidden / gate column blocks inside a wave");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;          // waves 0-3: rows 0-127 (leading group), waves 4-7: rows 128-255 (lagging group)
+    const int l15 = lane & 15, g = lane >> 4;
+    const int lrow = lane >> 3, csrc = (lane & 7) ^ lrow;
+
+    const int ntn = p.N / BN;
+    const int ntm = (p.M + BM - 1) / BM;
+    const int ntiles = ntm * ntn;
+    const int G = gridDim.x;
+    const int nk = p.K / 64;
+    const int first = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, G));
+    const int my_tiles = (ntiles - first + G - 1) / G;
+    const int S = my_tiles * nk;                      // K tiles this workgroup multiplies, in stream order
+
+    // ---- descriptors ----------------------------------------------------------------------------------------------------------
+    const long a_bytes = AMODE == AMODE_DENSE ? (long)p.M * p.lda * 2 : (long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * 2;
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (int)((long)p.N * p.Kpad * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+    const int nbatch = (p.M + p.rows_per_batch - 1) / p.rows_per_batch;
+    const __amdgpu_buffer_rsrc_t rsrcRb =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.rowbias), 0, p.rowbias ? ((nbatch - 1) * p.ldrb + p.N) * 4 : 0, 0x00020000);
+    const long o_bytes = (long)p.M * p.ldo * 2;
+    const __amdgpu_buffer_rsrc_t rsrcO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)o_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, RES ? (int)((long)p.M * p.ldr * 2) : 0, 0x00020000);
+
+    // ---- loader: runs one K tile ahead of the multiplier along the stream (tile, kt) ------------------------------------------
+    // A pieces (8 rows x 128 B = one wave-instruction): [0] rows 8w.., [1] rows 128+8w.. (the "low" unit), [2] rows 64+8w..,
+    // [3] rows 192+8w.. (the "high" unit); B pieces rows 8(w + 8i)..
+    int l_tile = first, l_kt = 0;
+    int a_off[4];                                     // dense: byte offset of this lane's chunk at K = 0; conv: the same for tap (0,0), ignoring the image border
+    int a_yx[4];                                      // conv: packed (y << 16 | x & 0xffff) of the tap-(0,0) input pixel
+    int b_voff;
+    const int b_step = 64 * p.Kpad * 2;
+    constexpr int kApiece[4] = {0, 16, 8, 24};
+    // The position along K is a pure SCALAR function of the loader's K-tile counter (no loop-carried tap state: with `if (ka >= Cin)`
+    // style updates hipcc moved the whole tap state into VGPRs and put a v_readfirstlane + hazard nops, or a waterfall loop, in
+    // front of every load).  cpt = 64-channel chunks per tap; tap = l_kt / cpt by a 16-bit reciprocal (exact for l_kt * cpt < 65536).
+    const int cpt = AMODE == AMODE_DENSE ? 1 : p.Cin / 64;
+    const int cpt_rcp = (65536 + cpt - 1) / cpt;
+    int ka = 0, tap_ky = 0, tap_kx = 0, tap_off = 0;  // of K tile l_kt; set by k_position()
+    auto k_position = [&]() {
+        if (AMODE == AMODE_DENSE) {
+            ka = l_kt * 128;
+        } else {
+            const int tap = (l_kt * cpt_rcp) >> 16;
+            ka = (l_kt - tap * cpt) * 128;
+            tap_ky = (tap * 21846) >> 16;
+            tap_kx = tap - 3 * tap_ky;
+            tap_off = (tap_ky * p.Win + tap_kx) * p.Cin * 2;
+        }
+    };
+    auto prep = [&](int tile) {                       // loader state at K tile 0 of output tile `tile`
+        const int mt = (tile / ntn) * BM, nt = (tile % ntn) * BN;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mt + 8 * (kApiece[i] + wave) + lrow;
+            if (AMODE == AMODE_DENSE) {
+                a_off[i] = m < p.M ? m * (p.lda * 2) + csrc * 16 : OOB;
+            } else {
+                const int hw = p.Hout * p.Wout;
+                const int b = m / hw, rem = m - b * hw;
+                const int yo = rem / p.Wout, xo = rem - yo * p.Wout;
+                const int y0 = yo * p.stride - p.pad, x0 = xo * p.stride - p.pad;
+                a_off[i] = ((b * p.Hin + y0) * p.Win + x0) * (p.Cin * 2) + csrc * 16;
+                a_yx[i] = m < p.M ? ((y0 << 16) | (x0 & 0xffff)) : (int)0x80008000;       // rows past M: every tap out of the image
+            }
+        }
+        b_voff = (nt + 8 * wave + lrow) * (p.Kpad * 2) + csrc * 16;
+    };
+    auto issue_a = [&](int i, int buf) {
+        int voff = a_off[i];
+        if (AMODE != AMODE_DENSE) {
+            const int yy = (a_yx[i] >> 16) + tap_ky, xx = (int)(short)(a_yx[i] & 0xffff) + tap_kx;
+            const bool inb = (unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
+            voff = inb ? voff + tap_off : OOB;
+        }
+        if (PP_ABL != 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)(smem + buf * BUF + (kApiece[i] + wave) * 1024), 16, voff, ka, 0, 0);
+    };
+    auto issue_b = [&](int i, int buf) {
+        if (PP_ABL != 1)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(smem + buf * BUF + ABYTES + (wave + 8 * i) * 1024), 16, b_voff, l_kt * 128 + i * b_step, 0, 0);
+    };
+    // column vectors of output tile `tile` for THIS wave: bias[n0 + wc*WN ..) and rowbias[batch of the wave's rows][same columns),
+    // 2 x 64 floats each (lanes past WN fetch nothing: zeros), into the wave's private 1 KiB slot
+    auto issue_colvec = [&](int tile) {
+        const int mt = (tile / ntn) * BM + wr * 128, nt = (tile % ntn) * BN + wc * WN;
+        const int bb = mt / p.rows_per_batch;
+        char* slot = smem + CV + wave * 1024;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = h * 64 + lane;
+            const int vb = c < WN ? (nt + c) * 4 : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcBias, (lptr_t)(slot + h * 256), 4, vb, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcRb, (lptr_t)(slot + 512 + h * 256), 4, vb, bb * p.ldrb * 4, 0, 0);
+        }
+    };
+    int switched = 0;
+    auto advance = [&]() {                            // after the last piece of a K tile was requested: step the stream
+        ++l_kt;
+        switched = 0;
+        if (l_kt == nk) {
+            l_kt = 0;
+            l_tile += G;
+            if (l_tile < ntiles) {
+                prep(l_tile);
+                issue_colvec(l_tile);
+                switched = 1;
+            }
+        }
+    };
+
+    // ---- multiplier state ------------------------------------------------------------------------------------------------
+    const int swz = l15 & 7;
+    const int a_rd0 = (wr * 128 + l15) * 128 + ((g ^ swz) << 4);           // k-substep 0; fragment i adds i * 2048
+    const int a_rd1 = (wr * 128 + l15) * 128 + (((4 + g) ^ swz) << 4);
+    const int b_rd0 = ABYTES + (wc * WN + l15) * 128 + ((g ^ swz) << 4);
+    const int b_rd1 = ABYTES + (wc * WN + l15) * 128 + (((4 + g) ^ swz) << 4);
+
+    f32x4 acc[8][FN];
+    u32x4 fa[4], fb[FN];
+
+    auto read_a = [&](int buf, int rd, int i0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(smem + buf * BUF + rd + (i0 + i) * 2048);
+    };
+    auto read_b = [&](int buf, int rd) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const u32x4*>(smem + buf * BUF + rd + j * 2048);
+    };
+    auto mfma_rows = [&](auto I0) {
+        constexpr int i0 = decltype(I0)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) DT<T>::mma(fb[j], fa[i], acc[i0 + i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    typedef std::integral_constant<int, 0> I0_t;
+    typedef std::integral_constant<int, 4> I4_t;
+
+    // accumulators of a new output tile start at bias + row bias (+ residual): lane holds C[m = 16 i + l15][n = 16 j + 4 g + r]
+    auto init_acc = [&](int tile) {
+        const char* slot = smem + CV + wave * 1024;
+        f32x4 cv[FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            cv[j] = *reinterpret_cast<const f32x4*>(slot + (j * 16 + 4 * g) * 4);
+            cv[j] += *reinterpret_cast<const f32x4*>(slot + 512 + (j * 16 + 4 * g) * 4);
+        }
+        if constexpr (RES) {
+            const int m0 = (tile / ntn) * BM + wr * 128, n0 = (tile % ntn) * BN + wc * WN;
+            const int voff = (l15 * p.ldr + 4 * g) * 2;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                u32x2 w[FN];
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    w[j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrcR, voff, ((m0 + i * 16) * p.ldr + n0 + j * 16) * 2, 0));
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    acc[i][j][0] = cv[j][0] + __uint_as_float(w[j][0] << 16);
+                    acc[i][j][1] = cv[j][1] + __uint_as_float(w[j][0] & 0xffff0000u);
+                    acc[i][j][2] = cv[j][2] + __uint_as_float(w[j][1] << 16);
+                    acc[i][j][3] = cv[j][3] + __uint_as_float(w[j][1] & 0xffff0000u);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = cv[j];
+        }
+    };
+    // epilogue: convert and store (rows past M fall outside the descriptor and are dropped by the range check)
+    auto store_tile = [&](int tile) {
+        const int m0 = (tile / ntn) * BM + wr * 128, n0 = (tile % ntn) * BN + wc * WN;
+        const int voff = (l15 * p.ldo + 4 * g) * 2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if constexpr (GEGLU) {
+#pragma unroll
+                for (int j = 0; j + 1 < FN; j += 2) {
+                    u32x2 w;
+                    w[0] = pack_bf16x2(acc[i][j][0] * gelu_for<T>(acc[i][j + 1][0]), acc[i][j][1] * gelu_for<T>(acc[i][j + 1][1]));
+                    w[1] = pack_bf16x2(acc[i][j][2] * gelu_for<T>(acc[i][j + 1][2]), acc[i][j][3] * gelu_for<T>(acc[i][j + 1][3]));
+                    __builtin_amdgcn_raw_buffer_store_b64(w, rsrcO, voff, ((m0 + i * 16) * p.ldo + n0 / 2 + (j / 2) * 16) * 2, 0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    u32x2 w;
+                    w[0] = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+                    w[1] = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+                    __builtin_amdgcn_raw_buffer_store_b64(w, rsrcO, voff, ((m0 + i * 16) * p.ldo + n0 + j * 16) * 2, 0);
+                }
+            }
+        }
+    };
+
+    // ---- prologue: K tile 0 of the stream and the first tile's column vectors, fully landed -----------------------------------
+    prep(l_tile);
+    issue_colvec(l_tile);
+#pragma unroll
+    for (int i = 0; i < FN; ++i) issue_b(i, 0);
+    k_position();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_a(i, 0);
+    advance();
+    pp_wait_vmcnt<0>();
+    pp_barrier();
+    if (wr == 1) pp_barrier();                        // the lagging group starts one barrier late
+
+    int c_tile = first, c_kt = 0, buf = 0;
+    init_acc(c_tile);
+    for (int s = 0; s < S; ++s) {
+        const bool more = s + 1 < S;                  // another K tile follows in this workgroup's stream: request it during this one
+        const int nb = buf ^ 1;
+
+        // ---- phase 1: rows 0-63, k-substep 0 ----
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(buf, a_rd0, 0);
+        read_b(buf, b_rd0);
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < NB1; ++i) issue_b(i, nb);
+            pp_wait_vmcnt<NB1>();                     // A-high of THIS K tile (requested in phase 4 of the previous one) has landed
+        } else {
+            pp_wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+        mfma_rows(I0_t{});
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+
+        // ---- phase 2: rows 64-127, k-substep 0 ----
+        read_a(buf, a_rd0, 4);
+        if (more) {
+#pragma unroll
+            for (int i = NB1; i < FN; ++i) issue_b(i, nb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+        mfma_rows(I4_t{});
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+
+        // ---- phase 3: rows 0-63, k-substep 1 ----
+        read_a(buf, a_rd1, 0);
+        read_b(buf, b_rd1);
+        if (more) {
+            k_position();
+            issue_a(0, nb);
+            issue_a(1, nb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+        mfma_rows(I0_t{});
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+
+        // ---- phase 4: rows 64-127, k-substep 1 ----
+        read_a(buf, a_rd1, 4);
+        if (more) {
+            issue_a(2, nb);
+            issue_a(3, nb);
+            advance();
+            // B and A-low of the next K tile have landed (A-high, and the next output tile's column vectors, may still be in flight)
+            if (switched) pp_wait_vmcnt<6>();
+            else pp_wait_vmcnt<2>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+        mfma_rows(I4_t{});
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+
+        buf = nb;
+        if (++c_kt == nk) {                           // output tile complete
+            store_tile(c_tile);
+            c_kt = 0;
+            c_tile += G;
+            if (more) init_acc(c_tile);
+        }
+    }
+    if (wr == 0) pp_barrier();                        // balance the lagging group's extra barrier
+}

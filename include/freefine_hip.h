@@ -10,7 +10,11 @@
  *   - every pointer is a DEVICE pointer owned by the caller (e.g. the torch caching allocator); the library never
  *     allocates, frees or retains memory; scratch is passed in explicitly;
  *   - every call enqueues on the hipStream_t given as `stream` (void* so the header needs no HIP include), is
- *     asynchronous with respect to the host and performs no synchronisation -> capturable in a hipGraph;
+ *     asynchronous with respect to the host and performs no synchronisation -> capturable in a hipGraph.  ONE exception:
+ *     ffn_igemm in bf16, the FIRST time it sees a problem shape outside stream capture, times its candidate configurations on the
+ *     stream (it synchronises the stream, rewrites `out` several times and holds a process-wide lock while it does); call
+ *     ffn_igemm_tune() for every shape during warm-up -- or set FFN_IGEMM_TUNE=0 -- where that must not happen later (worker threads,
+ *     latency-sensitive replays, runs that need identical tile choices on every rank);
  *   - return value 0 = success, negative = error (FFN_E*); ffn_last_error() returns a thread-local message;
  *   - dtype selects the element type of activations / weights: FFN_F32 (exact fp32 MFMA, "parity mode") or
  *     FFN_BF16 (bf16 MFMA operands, fp32 accumulation, "fast mode").  Norm parameters, biases, masks-as-weights,
@@ -66,6 +70,8 @@ int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
  * configurations on the caller's stream (this one call synchronises the stream and launches the kernel several times: `out` must
  * not alias `residual`) and caches the winner; FFN_IGEMM_TUNE=0 in the environment keeps the deterministic rule-based choice
  * (f32 always uses it).  Testing hooks: the number of bf16 configurations, and forcing one (-1 = off; returns the previous value). */
+/* explicit warm-up entry point: tunes (or looks up) the configuration for `d` now, exactly as the first ffn_igemm call would */
+int ffn_igemm_tune(void* stream, int dtype, const ffn_igemm_desc* d);
 int ffn_igemm_num_configs(void);
 int ffn_igemm_force_config(int cfg);
 /* which tile (BM x BN) ffn_igemm dispatches for this problem -- lets a profiler name the kernel instantiation */

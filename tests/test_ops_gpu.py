@@ -426,6 +426,16 @@ def test_every_bf16_igemm_configuration(gpu):
             ref = torch.nn.functional.conv2d(xr, w.double().cpu(), b.double().cpu(), padding=1) + rb.double().cpu()[:, :, None, None]
             ref = ref.permute(0, 2, 3, 1).reshape(B, H * H, Cout) + r.double().cpu()
             assert relerr(out, ref) < tol(dt), (cfg, "conv")
+            # shapes the ping-pong kernel accepts (256-row tiles, N % 320 == 0 or N % 256 == 0, rows per image % 128 == 0), with the
+            # time-embedding row bias arriving through its LDS column vectors and the residual through its accumulator start values
+            for (B, H, W, Cin, Cout) in [(3, 32, 32, 128, 320), (2, 16, 48, 64, 512), (5, 16, 16, 192, 640)]:
+                x, w = rnd((B, H * W, Cin), dt, gpu, g), rnd((Cout, Cin, 3, 3), dt, gpu, g, (9 * Cin) ** -0.5)
+                b, rb, r = rnd((Cout,), torch.float32, gpu, g), rnd((B, Cout), torch.float32, gpu, g), rnd((B, H * W, Cout), dt, gpu, g)
+                out = ops.conv3x3(x, ops.pack_conv3x3(w, dt), b, B, H, W, Cin, rowbias=rb, residual=r)
+                xr = x.double().cpu().reshape(B, H, W, Cin).permute(0, 3, 1, 2)
+                ref = torch.nn.functional.conv2d(xr, w.double().cpu(), b.double().cpu(), padding=1) + rb.double().cpu()[:, :, None, None]
+                ref = ref.permute(0, 2, 3, 1).reshape(B, H * W, Cout) + r.double().cpu()
+                assert relerr(out, ref) < tol(dt), (cfg, "conv-pp-shapes", H, W, Cout)
             # shapes the halo conv kernel accepts: tiles of whole image rows (32x32, 16x16) and pieces of one wide row (4x256)
             for (B, H, W, Cin, Cout) in [(2, 32, 32, 128, 320), (3, 16, 16, 192, 256), (1, 4, 256, 64, 128)]:
                 x, w = rnd((B, H * W, Cin), dt, gpu, g), rnd((Cout, Cin, 3, 3), dt, gpu, g, (9 * Cin) ** -0.5)
