@@ -241,23 +241,23 @@ extern "C" int ffn_attn_variant(int dtype, int D, int* dp, int* qf) {
 // runs the N = 320 convs at 850-1000 TFLOP/s where 128x128 -- 17% of its third column tile wasted -- gives 690-760; 256x256
 // reaches 1190 on N = 1280 but loses 20% on N = 640).  So the first time a problem shape is seen outside stream capture, the
 // few plausible configurations are timed on the caller's stream with the caller's buffers and the winner is cached.
-enum { CFG_64x64, CFG_128x64, CFG_128x128_8, CFG_128x128_16, CFG_256x128, CFG_256x256, CFG_128x320, CFG_128x160, CFG_192x320, CFG_H_128x320, CFG_H_256x128, CFG_H_256x256, CFG_H_128x128, CFG_PP_256x320, CFG_PP_256x256, CFG_COUNT };
+enum { CFG_64x64, CFG_128x64, CFG_128x128_8, CFG_128x128_16, CFG_256x128, CFG_256x256, CFG_128x320, CFG_128x160, CFG_192x320, CFG_H_128x320, CFG_H_256x128, CFG_H_256x256, CFG_H_128x128, CFG_PP_256x320, CFG_PP_256x256, CFG_PP_192x320, CFG_PP_192x256, CFG_COUNT };
 struct IgCfgInfo { int bm, bn, nwm, nwn; };
 static const IgCfgInfo kCfg[CFG_COUNT] = {{64, 64, 2, 2}, {128, 64, 4, 2}, {128, 128, 2, 4}, {128, 128, 4, 4},
                                           {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 320, 4, 4}, {128, 160, 4, 2}, {192, 320, 3, 4},
                                           {128, 320, 4, 4}, {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 128, 4, 4},    // halo kernel (3x3 stride-1 convs)
-                                          {256, 320, 2, 4}, {256, 256, 2, 4}};                                         // ping-pong kernel (igemm_p8.h)
+                                          {256, 320, 2, 4}, {256, 256, 2, 4}, {192, 320, 2, 4}, {192, 256, 2, 4}};     // ping-pong kernel (igemm_p8.h)
 struct IgChoice { int cfg, splitk; };
 
 static bool is_halo_cfg(int cfg) { return cfg == CFG_H_128x320 || cfg == CFG_H_256x128 || cfg == CFG_H_256x256 || cfg == CFG_H_128x128; }
-static bool is_pp_cfg(int cfg) { return cfg == CFG_PP_256x320 || cfg == CFG_PP_256x256; }
-// whether the ping-pong kernel (igemm_p8.h) handles this problem on a 256 x bn tile: its restrictions are listed in that header
-static bool pp_ok(const ffn_igemm_desc& d, int bn) {
+static bool is_pp_cfg(int cfg) { return cfg >= CFG_PP_256x320 && cfg <= CFG_PP_192x256; }
+// whether the ping-pong kernel (igemm_p8.h) handles this problem on a bm x bn tile: its restrictions are listed in that header
+static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn) {
     const long lim = (1l << 31) - 4096;
-    if (d.K % 64 != 0 || d.K < 128 || d.N % bn != 0 || d.alpha != 1.0f || d.M < 256) return false;
+    if (d.K % 64 != 0 || d.K < 128 || d.N % bn != 0 || d.alpha != 1.0f || d.M < bm) return false;
     if (d.flags & ~FFN_IG_GEGLU) return false;
     if ((d.flags & FFN_IG_GEGLU) && bn != 256) return false;
-    if (d.rowbias && d.rows_per_batch % 128 != 0) return false;
+    if (d.rowbias && d.rows_per_batch < 128) return false;      // a wave's rows (bm / 2) may straddle two images, not three
     long a_bytes;
     if (d.conv) {
         if (d.Cin % 64 != 0 || d.upsample || d.K != 9 * d.Cin || d.Cin / 64 * 9 * (d.Cin / 64) >= 65536) return false;
@@ -314,31 +314,39 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
         FFN_CFG_CASE(CFG_128x160, 128, 160, 4, 2)
         FFN_CFG_CASE(CFG_192x320, 192, 320, 3, 4)      // 12 waves: 168 registers per wave (spills at 16 waves x 128)
         case CFG_PP_256x320:
-        case CFG_PP_256x256: {
-            if (!pp_ok(d, c.bn) || ch.splitk != 1) return fail(FFN_EINVAL, "igemm: ping-pong kernel not applicable");
-            const int pplds = 2 * (256 + c.bn) * 128 + 8192;
-            const int nt = ((d.M + 255) / 256) * (d.N / c.bn);
+        case CFG_PP_256x256:
+        case CFG_PP_192x320:
+        case CFG_PP_192x256: {
+            if (!pp_ok(d, c.bm, c.bn) || ch.splitk != 1) return fail(FFN_EINVAL, "igemm: ping-pong kernel not applicable");
+            const int pplds = 2 * (c.bm + c.bn) * 128 + 12288;
+            const int nt = ((d.M + c.bm - 1) / c.bm) * (d.N / c.bn);
             const int grid = nt < device_cus() ? nt : device_cus();
             (void)hipGetLastError();
-#define FFN_PP_LAUNCH(BN_, RES_, GEGLU_)                                                   \
+#define FFN_PP_LAUNCH(BM_, BN_, RES_, GEGLU_)                                              \
     do {                                                                                   \
-        auto kern = igemm_pp_kernel<BN_, AMODE, RES_, GEGLU_>;                             \
+        auto kern = igemm_pp_kernel<BM_, BN_, AMODE, RES_, GEGLU_>;                        \
         if ((rc = set_lds(kern, pplds))) return rc;                                        \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pplds, s, d);                      \
     } while (0)
-            if (ch.cfg == CFG_PP_256x320) {
-                if (d.residual) FFN_PP_LAUNCH(320, true, false);
-                else FFN_PP_LAUNCH(320, false, false);
-            } else {
-                if constexpr (AMODE == AMODE_DENSE) {
-                    if (d.flags & FFN_IG_GEGLU) FFN_PP_LAUNCH(256, false, true);
-                    else if (d.residual) FFN_PP_LAUNCH(256, true, false);
-                    else FFN_PP_LAUNCH(256, false, false);
-                } else {
-                    if (d.residual) FFN_PP_LAUNCH(256, true, false);
-                    else FFN_PP_LAUNCH(256, false, false);
-                }
-            }
+#define FFN_PP_TILE(BM_)                                                                   \
+    do {                                                                                   \
+        if (c.bn == 320) {                                                                 \
+            if (d.residual) FFN_PP_LAUNCH(BM_, 320, true, false);                          \
+            else FFN_PP_LAUNCH(BM_, 320, false, false);                                    \
+        } else {                                                                           \
+            if constexpr (AMODE == AMODE_DENSE) {                                          \
+                if (d.flags & FFN_IG_GEGLU) FFN_PP_LAUNCH(BM_, 256, false, true);          \
+                else if (d.residual) FFN_PP_LAUNCH(BM_, 256, true, false);                 \
+                else FFN_PP_LAUNCH(BM_, 256, false, false);                                \
+            } else {                                                                       \
+                if (d.residual) FFN_PP_LAUNCH(BM_, 256, true, false);                      \
+                else FFN_PP_LAUNCH(BM_, 256, false, false);                                \
+            }                                                                              \
+        }                                                                                  \
+    } while (0)
+            if (c.bm == 256) FFN_PP_TILE(256);
+            else FFN_PP_TILE(192);
+#undef FFN_PP_TILE
 #undef FFN_PP_LAUNCH
             return check_launch("igemm(ping-pong)");
         }
@@ -438,7 +446,7 @@ static int candidates_for(const ffn_igemm_desc& d, IgChoice* out, int cap) {
             if ((cfg == CFG_H_128x320) && (d.flags & FFN_IG_GEGLU)) continue;
         }
         const bool halo = is_halo_cfg(cfg) || is_pp_cfg(cfg);                      // no split-K variants
-        if (is_pp_cfg(cfg) && (!pp_ok(d, c.bn) || d.splitk > 1)) continue;
+        if (is_pp_cfg(cfg) && (!pp_ok(d, c.bm, c.bn) || d.splitk > 1)) continue;
         if (c.bm > 64 && c.bm >= 2 * d.M) continue;                                // tile mostly empty
         if (c.bn > 64 && c.bn >= 2 * d.N) continue;
         if (cfg == CFG_64x64 && (long)d.M * d.N > (1l << 22)) continue;
@@ -477,8 +485,8 @@ extern "C" int ffn_igemm_force_config(int cfg) {
 template <int AMODE>
 static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
     if (g_force_cfg >= 0) {
-        IgChoice cand[24];
-        const int nc = candidates_for(d, cand, 24);
+        IgChoice cand[40];
+        const int nc = candidates_for(d, cand, 40);
         for (int i = 0; i < nc; ++i)
             if (cand[i].cfg == g_force_cfg) return launch_bf16_cfg<AMODE>(s, d, cand[i]);
         return launch_bf16_cfg<AMODE>(s, d, heuristic_choice(d));     // not valid for this problem
@@ -494,8 +502,8 @@ static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
     }
     if (!tune_enabled() || cap != hipStreamCaptureStatusNone || aliased) return launch_bf16_cfg<AMODE>(s, d, heuristic_choice(d));
     std::lock_guard<std::mutex> lk(g_tune_mu);       // one tuning at a time
-    IgChoice cand[24];
-    const int nc = candidates_for(d, cand, 24);
+    IgChoice cand[40];
+    const int nc = candidates_for(d, cand, 40);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return launch_bf16_cfg<AMODE>(s, d, cand[0]);
     IgChoice best = cand[0];
@@ -546,7 +554,7 @@ extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d, char* b
             return FFN_OK;
         }
         if (is_pp_cfg(ch.cfg)) {
-            snprintf(buf, len, "void igemm_pp_kernel<%d, %d, %s, %s>(ffn_igemm_desc)", c.bn, d->conv ? 1 : 0, d->residual ? "true" : "false",
+            snprintf(buf, len, "void igemm_pp_kernel<%d, %d, %d, %s, %s>(ffn_igemm_desc)", c.bm, c.bn, d->conv ? 1 : 0, d->residual ? "true" : "false",
                      (d->flags & FFN_IG_GEGLU) ? "true" : "false");
             return FFN_OK;
         }

@@ -4,8 +4,10 @@
 // an empty load pipe, and the two waves of a SIMD run their MFMA chains and their LDS reads in lockstep.  Measured (profiles/,
 // round 1): 39-46 % MFMA busy, ~50 % of wave cycles parked in s_waitcnt / s_barrier, the L2->LDS path idle between stages.  This
 // kernel is built the way cdna_hip_programming.md section 5 ("256^2 8-phase template", T3+T4+T5) describes:
-//   * 256 x BN output tile (BN = 256 or 320), 8 waves as 2 (M) x 4 (N), 128 x BN/4 outputs per wave (128 or 160 accumulator
-//     registers), one workgroup per CU, LDS = two whole K tiles (2 x (256 + BN) x 128 B = 128 / 144 KiB) + 8 KiB of column vectors;
+//   * BM x BN output tile (BM = 256 or 192 -- the tile HEIGHT is a launch-time choice so that the tile count lands on a multiple of
+//     the 256 CUs: M = 98304 gives 384 tiles of 256 rows = 1.5 rounds, but 512 of 192 = 2 full rounds --, BN = 256 or 320), 8 waves
+//     as 2 (M) x 4 (N), BM/2 x BN/4 outputs per wave (96-160 accumulator registers), one workgroup per CU, LDS = two whole K tiles
+//     (2 x (BM + BN) x 128 B <= 144 KiB) + 12 KiB of column vectors;
 //   * a K tile (64 deep) is consumed in FOUR phases (k-substep 0: rows 0-63 of the wave, rows 64-127; k-substep 1: same), 16 or 20
 //     MFMAs each; the B fragments of a k-substep stay in registers for its two phases;
 //   * the next K tile's operands are requested in the SAME four phases (B, B, A rows {0-63,128-191}, A rows {64-127,192-255}: 2-3
@@ -39,7 +41,7 @@
 // on gfx950: tools/native/probe_bufload_lds.hip), so there is no zero page and no select.
 //
 // Restrictions (checked by the launcher, capi.hip): bf16; K % 64 == 0 and K >= 128 (conv: Cin % 64 == 0); N % BN == 0; alpha == 1;
-// flags subset of {GEGLU (BN = 256)}; no upsampling conv; rowbias only with rows_per_batch % 128 == 0; every operand < 2 GiB.
+// flags subset of {GEGLU (BN = 256)}; no upsampling conv; rowbias only with rows_per_batch >= 128; every operand < 2 GiB.
 #pragma once
 #include <type_traits>
 #include "igemm.h"
@@ -57,24 +59,27 @@ __device__ __forceinline__ void pp_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int BN, int AMODE, bool RES, bool GEGLU>
+template <int BM, int BN, int AMODE, bool RES, bool GEGLU>
 __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
     typedef bf16 T;
-    constexpr int BM = 256;
+    constexpr int HM = BM / 2;              // rows per wave (128 or 96)
+    constexpr int FM = HM / 16;             // 16-row fragments per wave (8 or 6), FH of them per phase
+    constexpr int FH = FM / 2;
+    constexpr int NA = BM / 64;             // A pieces per wave and K tile (4 or 3): 2 requested in phase 3, NA - 2 in phase 4
     constexpr int FN = BN / 64;             // 16-column fragments per wave (4 or 5)
     constexpr int WN = BN / 4;              // columns per wave
     constexpr int ABYTES = BM * 128, BBYTES = BN * 128, BUF = ABYTES + BBYTES;
-    constexpr int CV = 2 * BUF;             // column vectors: per wave [bias | row bias] x 128 floats
+    constexpr int CV = 2 * BUF;             // column vectors: per wave [bias | row bias of the first image | of the next image] x 128 floats
     constexpr int NB1 = (FN + 1) / 2;       // B pieces requested in phase 1 (the rest in phase 2)
     constexpr int OOB = (int)0x80000000;
-    static_assert(BN == 256 || BN == 320, "tile widths built for this kernel");
+    static_assert((BM == 256 || BM == 192) && (BN == 256 || BN == 320), "tiles built for this kernel");
     static_assert(!GEGLU || FN % 2 == 0, "GEGLU pairs hidden / gate column blocks inside a wave");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;          // waves 0-3: rows 0-127 (leading group), waves 4-7: rows 128-255 (lagging group)
+    const int wr = wave >> 2, wc = wave & 3;          // waves 0-3: upper half of the rows (leading group), waves 4-7: lower half (lagging group)
     const int l15 = lane & 15, g = lane >> 4;
     const int lrow = lane >> 3, csrc = (lane & 7) ^ lrow;
 
@@ -100,14 +105,24 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
     const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, RES ? (int)((long)p.M * p.ldr * 2) : 0, 0x00020000);
 
     // ---- loader: runs one K tile ahead of the multiplier along the stream (tile, kt) ------------------------------------------
-    // A pieces (8 rows x 128 B = one wave-instruction): [0] rows 8w.., [1] rows 128+8w.. (the "low" unit), [2] rows 64+8w..,
-    // [3] rows 192+8w.. (the "high" unit); B pieces rows 8(w + 8i)..
+    // A pieces (8 rows x 128 B = one wave-instruction).  The rows each wave multiplies in phases 1 and 3 ("low": the first HM/2 rows
+    // of either wave group) must have landed one phase earlier than the rest ("high"), so every low piece is requested in phase 3:
+    //   BM = 256: wave w requests pieces {w, 16+w} (low) in phase 3 and {8+w, 24+w} (high) in phase 4;
+    //   BM = 192: low = pieces 0-5 and 12-17, high = 6-11 and 18-23; phase 3 takes the 12 low ones and 4 high ones, phase 4 the rest.
+    // B pieces: rows 8(w + 8i)..
     int l_tile = first, l_kt = 0;
-    int a_off[4];                                     // dense: byte offset of this lane's chunk at K = 0; conv: the same for tap (0,0), ignoring the image border
-    int a_yx[4];                                      // conv: packed (y << 16 | x & 0xffff) of the tap-(0,0) input pixel
+    int a_off[NA];                                    // dense: byte offset of this lane's chunk at K = 0; conv: the same for tap (0,0), ignoring the image border
+    int a_yx[NA];                                     // conv: packed (y << 16 | x & 0xffff) of the tap-(0,0) input pixel
     int b_voff;
     const int b_step = 64 * p.Kpad * 2;
-    constexpr int kApiece[4] = {0, 16, 8, 24};
+    int apiece[NA];
+    if constexpr (BM == 256) {
+        apiece[0] = wave; apiece[1] = 16 + wave; apiece[2] = 8 + wave; apiece[3] = 24 + wave;
+    } else {
+        apiece[0] = wave < 6 ? wave : wave + 6;
+        apiece[1] = wave < 4 ? 14 + wave : 2 + wave;
+        apiece[2] = wave < 2 ? 10 + wave : 16 + wave;
+    }
     // The position along K is a pure SCALAR function of the loader's K-tile counter (no loop-carried tap state: with `if (ka >= Cin)`
     // style updates hipcc moved the whole tap state into VGPRs and put a v_readfirstlane + hazard nops, or a waterfall loop, in
     // front of every load).  cpt = 64-channel chunks per tap; tap = l_kt / cpt by a 16-bit reciprocal (exact for l_kt * cpt < 65536).
@@ -128,8 +143,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
     auto prep = [&](int tile) {                       // loader state at K tile 0 of output tile `tile`
         const int mt = (tile / ntn) * BM, nt = (tile % ntn) * BN;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = mt + 8 * (kApiece[i] + wave) + lrow;
+        for (int i = 0; i < NA; ++i) {
+            const int m = mt + 8 * apiece[i] + lrow;
             if (AMODE == AMODE_DENSE) {
                 a_off[i] = m < p.M ? m * (p.lda * 2) + csrc * 16 : OOB;
             } else {
@@ -150,24 +165,26 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
             const bool inb = (unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
             voff = inb ? voff + tap_off : OOB;
         }
-        if (PP_ABL != 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)(smem + buf * BUF + (kApiece[i] + wave) * 1024), 16, voff, ka, 0, 0);
+        if (PP_ABL != 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)(smem + buf * BUF + apiece[i] * 1024), 16, voff, ka, 0, 0);
     };
     auto issue_b = [&](int i, int buf) {
         if (PP_ABL != 1)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(smem + buf * BUF + ABYTES + (wave + 8 * i) * 1024), 16, b_voff, l_kt * 128 + i * b_step, 0, 0);
     };
-    // column vectors of output tile `tile` for THIS wave: bias[n0 + wc*WN ..) and rowbias[batch of the wave's rows][same columns),
-    // 2 x 64 floats each (lanes past WN fetch nothing: zeros), into the wave's private 1 KiB slot
+    // column vectors of output tile `tile` for THIS wave: bias[n0 + wc*WN ..) and the row bias of the (at most two: the launcher
+    // requires rows_per_batch >= HM) images the wave's HM rows belong to, 2 x 64 floats each (lanes past WN fetch nothing: zeros),
+    // into the wave's private 1.5 KiB slot.  6 loads per wave.
     auto issue_colvec = [&](int tile) {
-        const int mt = (tile / ntn) * BM + wr * 128, nt = (tile % ntn) * BN + wc * WN;
+        const int mt = (tile / ntn) * BM + wr * HM, nt = (tile % ntn) * BN + wc * WN;
         const int bb = mt / p.rows_per_batch;
-        char* slot = smem + CV + wave * 1024;
+        char* slot = smem + CV + wave * 1536;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int c = h * 64 + lane;
             const int vb = c < WN ? (nt + c) * 4 : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcBias, (lptr_t)(slot + h * 256), 4, vb, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcRb, (lptr_t)(slot + 512 + h * 256), 4, vb, bb * p.ldrb * 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcRb, (lptr_t)(slot + 1024 + h * 256), 4, vb, (bb + 1) * p.ldrb * 4, 0, 0);
         }
     };
     int switched = 0;
@@ -187,17 +204,17 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
 
     // ---- multiplier state ------------------------------------------------------------------------------------------------
     const int swz = l15 & 7;
-    const int a_rd0 = (wr * 128 + l15) * 128 + ((g ^ swz) << 4);           // k-substep 0; fragment i adds i * 2048
-    const int a_rd1 = (wr * 128 + l15) * 128 + (((4 + g) ^ swz) << 4);
+    const int a_rd0 = (wr * HM + l15) * 128 + ((g ^ swz) << 4);            // k-substep 0; fragment i adds i * 2048
+    const int a_rd1 = (wr * HM + l15) * 128 + (((4 + g) ^ swz) << 4);
     const int b_rd0 = ABYTES + (wc * WN + l15) * 128 + ((g ^ swz) << 4);
     const int b_rd1 = ABYTES + (wc * WN + l15) * 128 + (((4 + g) ^ swz) << 4);
 
-    f32x4 acc[8][FN];
-    u32x4 fa[4], fb[FN];
+    f32x4 acc[FM][FN];
+    u32x4 fa[FH], fb[FN];
 
     auto read_a = [&](int buf, int rd, int i0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(smem + buf * BUF + rd + (i0 + i) * 2048);
+        for (int i = 0; i < FH; ++i) fa[i] = *reinterpret_cast<const u32x4*>(smem + buf * BUF + rd + (i0 + i) * 2048);
     };
     auto read_b = [&](int buf, int rd) {
 #pragma unroll
@@ -207,53 +224,55 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
         constexpr int i0 = decltype(I0)::value;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FH; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) DT<T>::mma(fb[j], fa[i], acc[i0 + i][j]);
         __builtin_amdgcn_s_setprio(0);
     };
     typedef std::integral_constant<int, 0> I0_t;
-    typedef std::integral_constant<int, 4> I4_t;
+    typedef std::integral_constant<int, FH> I4_t;
 
     // accumulators of a new output tile start at bias + row bias (+ residual): lane holds C[m = 16 i + l15][n = 16 j + 4 g + r]
     auto init_acc = [&](int tile) {
-        const char* slot = smem + CV + wave * 1024;
-        f32x4 cv[FN];
+        const char* slot = smem + CV + wave * 1536;
+        const int m0 = (tile / ntn) * BM + wr * HM, n0 = (tile % ntn) * BN + wc * WN;
+        const int edge = (m0 / p.rows_per_batch + 1) * p.rows_per_batch - m0 - l15;      // rows i with 16 i >= edge belong to the next image
+        f32x4 cv[FN], cv2[FN];
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            cv[j] = *reinterpret_cast<const f32x4*>(slot + (j * 16 + 4 * g) * 4);
-            cv[j] += *reinterpret_cast<const f32x4*>(slot + 512 + (j * 16 + 4 * g) * 4);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(slot + (j * 16 + 4 * g) * 4);
+            cv[j] = bv + *reinterpret_cast<const f32x4*>(slot + 512 + (j * 16 + 4 * g) * 4);
+            cv2[j] = bv + *reinterpret_cast<const f32x4*>(slot + 1024 + (j * 16 + 4 * g) * 4);
         }
-        if constexpr (RES) {
-            const int m0 = (tile / ntn) * BM + wr * 128, n0 = (tile % ntn) * BN + wc * WN;
-            const int voff = (l15 * p.ldr + 4 * g) * 2;
+        const int voff = (l15 * p.ldr + 4 * g) * 2;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < FM; ++i) {
+            const bool nxt = i * 16 >= edge;
+            if constexpr (RES) {
                 u32x2 w[FN];
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     w[j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrcR, voff, ((m0 + i * 16) * p.ldr + n0 + j * 16) * 2, 0));
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
-                    acc[i][j][0] = cv[j][0] + __uint_as_float(w[j][0] << 16);
-                    acc[i][j][1] = cv[j][1] + __uint_as_float(w[j][0] & 0xffff0000u);
-                    acc[i][j][2] = cv[j][2] + __uint_as_float(w[j][1] << 16);
-                    acc[i][j][3] = cv[j][3] + __uint_as_float(w[j][1] & 0xffff0000u);
+                    const f32x4 c = nxt ? cv2[j] : cv[j];
+                    acc[i][j][0] = c[0] + __uint_as_float(w[j][0] << 16);
+                    acc[i][j][1] = c[1] + __uint_as_float(w[j][0] & 0xffff0000u);
+                    acc[i][j][2] = c[2] + __uint_as_float(w[j][1] << 16);
+                    acc[i][j][3] = c[3] + __uint_as_float(w[j][1] & 0xffff0000u);
                 }
+            } else {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = nxt ? cv2[j] : cv[j];
             }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = cv[j];
         }
     };
     // epilogue: convert and store (rows past M fall outside the descriptor and are dropped by the range check)
     auto store_tile = [&](int tile) {
-        const int m0 = (tile / ntn) * BM + wr * 128, n0 = (tile % ntn) * BN + wc * WN;
+        const int m0 = (tile / ntn) * BM + wr * HM, n0 = (tile % ntn) * BN + wc * WN;
         const int voff = (l15 * p.ldo + 4 * g) * 2;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < FM; ++i) {
             if constexpr (GEGLU) {
 #pragma unroll
                 for (int j = 0; j + 1 < FN; j += 2) {
@@ -281,7 +300,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
     for (int i = 0; i < FN; ++i) issue_b(i, 0);
     k_position();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_a(i, 0);
+    for (int i = 0; i < NA; ++i) issue_a(i, 0);
     advance();
     pp_wait_vmcnt<0>();
     pp_barrier();
@@ -293,7 +312,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
         const bool more = s + 1 < S;                  // another K tile follows in this workgroup's stream: request it during this one
         const int nb = buf ^ 1;
 
-        // ---- phase 1: rows 0-63, k-substep 0 ----
+        // ---- phase 1: low rows, k-substep 0 ----
         __builtin_amdgcn_sched_barrier(0);
         read_a(buf, a_rd0, 0);
         read_b(buf, b_rd0);
@@ -310,8 +329,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
 
-        // ---- phase 2: rows 64-127, k-substep 0 ----
-        read_a(buf, a_rd0, 4);
+        // ---- phase 2: high rows, k-substep 0 ----
+        read_a(buf, a_rd0, FH);
         if (more) {
 #pragma unroll
             for (int i = NB1; i < FN; ++i) issue_b(i, nb);
@@ -322,7 +341,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
 
-        // ---- phase 3: rows 0-63, k-substep 1 ----
+        // ---- phase 3: low rows, k-substep 1 ----
         read_a(buf, a_rd1, 0);
         read_b(buf, b_rd1);
         if (more) {
@@ -336,15 +355,16 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
 
-        // ---- phase 4: rows 64-127, k-substep 1 ----
-        read_a(buf, a_rd1, 4);
+        // ---- phase 4: high rows, k-substep 1 ----
+        read_a(buf, a_rd1, FH);
         if (more) {
-            issue_a(2, nb);
-            issue_a(3, nb);
+#pragma unroll
+            for (int i = 2; i < NA; ++i) issue_a(i, nb);
             advance();
-            // B and A-low of the next K tile have landed (A-high, and the next output tile's column vectors, may still be in flight)
-            if (switched) pp_wait_vmcnt<6>();
-            else pp_wait_vmcnt<2>();
+            // B and A-low of the next K tile have landed (this phase's A-high pieces, and the next output tile's 6 column-vector
+            // loads, may still be in flight)
+            if (switched) pp_wait_vmcnt<NA - 2 + 6>();
+            else pp_wait_vmcnt<NA - 2>();
         }
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();

@@ -13,7 +13,7 @@ dev = torch.device("cuda:0")
 dt = torch.bfloat16
 g = torch.Generator().manual_seed(0)
 rnd = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(dt).to(dev)
-NAMES = ["64x64", "128x64", "128x128/8w", "128x128/16w", "256x128", "256x256", "128x320", "128x160", "192x320", "H128x320", "H256x128", "H256x256", "H128x128", "PP256x320", "PP256x256"]
+NAMES = ["64x64", "128x64", "128x128/8w", "128x128/16w", "256x128", "256x256", "128x320", "128x160", "192x320", "H128x320", "H256x128", "H256x256", "H128x128", "PP256x320", "PP256x256", "PP192x320", "PP192x256"]
 
 
 def timeit(fn, iters=20):

@@ -85,19 +85,23 @@ int main(int argc, char** argv) {
         if (conv) launch(igemm_glds_kernel<bf16, 256, 256, AMODE_CONV3, true, 2, 4, 4, true>, grid, 1024, 2 * (256 + 256) * 128, e);
         else launch(igemm_glds_kernel<bf16, 256, 256, AMODE_DENSE, true, 2, 4, 4, true>, grid, 1024, 2 * (256 + 256) * 128, e);
     };
+    const int bm = getenv("PP_BM") ? atoi(getenv("PP_BM")) : 256;
     auto run_pp = [&](void* out, int bn) {
         ffn_igemm_desc e = d; e.out = out;
-        const int nt = ((d.M + 255) / 256) * ((d.N + bn - 1) / bn);
+        const int nt = ((d.M + bm - 1) / bm) * (d.N / bn);
         const int grid = nt < 256 ? nt : 256;
-        const int lds = 2 * (256 + bn) * 128 + 8192;
-        if (bn == 320) {
-            if (conv) { if (e.residual) launch(igemm_pp_kernel<320, AMODE_CONV3, true, false>, grid, 512, lds, e); else launch(igemm_pp_kernel<320, AMODE_CONV3, false, false>, grid, 512, lds, e); }
-            else { if (e.residual) launch(igemm_pp_kernel<320, AMODE_DENSE, true, false>, grid, 512, lds, e); else launch(igemm_pp_kernel<320, AMODE_DENSE, false, false>, grid, 512, lds, e); }
-        } else {
-            if (conv) { if (e.residual) launch(igemm_pp_kernel<256, AMODE_CONV3, true, false>, grid, 512, lds, e); else launch(igemm_pp_kernel<256, AMODE_CONV3, false, false>, grid, 512, lds, e); }
-            else if (e.flags & FFN_IG_GEGLU) launch(igemm_pp_kernel<256, AMODE_DENSE, false, true>, grid, 512, lds, e);
-            else { if (e.residual) launch(igemm_pp_kernel<256, AMODE_DENSE, true, false>, grid, 512, lds, e); else launch(igemm_pp_kernel<256, AMODE_DENSE, false, false>, grid, 512, lds, e); }
+        const int lds = 2 * (bm + bn) * 128 + 12288;
+#define PPL(BM_, BN_, AM_, R_, G_) launch(igemm_pp_kernel<BM_, BN_, AM_, R_, G_>, grid, 512, lds, e)
+#define PPB(BM_)                                                                                                   \
+        if (bn == 320) {                                                                                           \
+            if (conv) { if (e.residual) PPL(BM_, 320, AMODE_CONV3, true, false); else PPL(BM_, 320, AMODE_CONV3, false, false); } \
+            else { if (e.residual) PPL(BM_, 320, AMODE_DENSE, true, false); else PPL(BM_, 320, AMODE_DENSE, false, false); }      \
+        } else {                                                                                                   \
+            if (conv) { if (e.residual) PPL(BM_, 256, AMODE_CONV3, true, false); else PPL(BM_, 256, AMODE_CONV3, false, false); } \
+            else if (e.flags & FFN_IG_GEGLU) PPL(BM_, 256, AMODE_DENSE, false, true);                              \
+            else { if (e.residual) PPL(BM_, 256, AMODE_DENSE, true, false); else PPL(BM_, 256, AMODE_DENSE, false, false); }      \
         }
+        if (bm == 256) { PPB(256) } else { PPB(192) }
     };
     const int bn = (d.N % 320 == 0 && !use_geglu) ? 320 : 256;
     if (use_geglu) run_ref256(dO0); else run_ref(dO0);
@@ -132,8 +136,8 @@ int main(int argc, char** argv) {
             CK(hipEventElapsedTime(&t[v], e0, e1));
             t[v] = t[v] * 1e3f / reps;
         }
-        printf("round %d: 128x320 %.1f us (%.0f TF)   256x256/16w %.1f us (%.0f TF)   pp256x%d %.1f us (%.0f TF)\n", round, t[0], flops / t[0] * 1e-6, t[1],
-               flops / t[1] * 1e-6, bn, t[2], flops / t[2] * 1e-6);
+        printf("round %d: 128x320 %.1f us (%.0f TF)   256x256/16w %.1f us (%.0f TF)   pp%dx%d %.1f us (%.0f TF)\n", round, t[0], flops / t[0] * 1e-6, t[1],
+               flops / t[1] * 1e-6, bm, bn, t[2], flops / t[2] * 1e-6);
     }
     return 0;
 }
