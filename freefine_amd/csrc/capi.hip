@@ -10,6 +10,7 @@
 
 #include "../../include/freefine_hip.h"
 #include "attention.h"
+#include "attention_pp.h"
 #include "elementwise.h"
 #include "igemm.h"
 #include "igemm_p8.h"
@@ -664,8 +665,29 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
         if (D <= 160) return launch_attn<float, 160, 1, 32>(s, *d);
     } else {
         bool masks = false;      // any (pass, row) entry with a key mask -> the kernel variant with the mask-on-MFMA tile
+        bool uniform = false;    // ... with a degenerate uniform-softmax query set (generic tile only)
         for (int pi = 0; pi < d->npass; ++pi)
-            for (int b = 0; b < d->Bo; ++b) masks |= d->e[pi * FFN_ATT_MAXB + b].kmask != nullptr;
+            for (int b = 0; b < d->Bo; ++b) {
+                const ffn_attn_entry& e = d->e[pi * FFN_ATT_MAXB + b];
+                if (e.w_const == 0.f && e.w_slope == 0.f) continue;
+                masks |= e.kmask != nullptr;
+                uniform |= e.kmask != nullptr && (e.flags & (FFN_ATT_UNIFORM_SEL1 | FFN_ATT_UNIFORM_SEL0));
+            }
+        // the ping-pong schedule (attention_pp.h): d = 64, whole 64-key tiles, at least one 256-query workgroup worth of queries
+        static const bool pp_on = [] { const char* e = getenv("FFN_ATTN_PP"); return !(e && atoi(e) == 0); }();
+        if (pp_on && D == 64 && d->Sk % 64 == 0 && d->S >= 128 && !uniform) {
+            constexpr int lds = 4 * 8192 + 4 * 8192 + 4 * 256 + 8 * 4 * 2 * 64 * 16;
+            dim3 grid(((d->S + 255) / 256) * d->heads * d->Bo);
+            int rc;
+            if (masks) {
+                if ((rc = set_lds(attn_pp_kernel<true>, lds))) return rc;
+                LAUNCH(attn_pp_kernel<true>, grid, dim3(512), lds, s, *d);
+            } else {
+                if ((rc = set_lds(attn_pp_kernel<false>, lds))) return rc;
+                LAUNCH(attn_pp_kernel<false>, grid, dim3(512), lds, s, *d);
+            }
+            return check_launch("attn(ping-pong)");
+        }
         if (D <= 64) return masks ? launch_attn<bf16, 64, 2, 64, 2, true>(s, *d) : launch_attn<bf16, 64, 2, 64, 2, false>(s, *d);
         if (D <= 96) return masks ? launch_attn<bf16, 96, 2, 64, 1, true>(s, *d) : launch_attn<bf16, 96, 2, 64, 1, false>(s, *d);
         if (D <= 160) return masks ? launch_attn<bf16, 160, 1, 64, 1, true>(s, *d) : launch_attn<bf16, 160, 1, 64, 1, false>(s, *d);
