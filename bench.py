@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tune-file", default=os.environ.get("FFN_IGEMM_TUNE_FILE", ""),
+                    help="igemm tuning table: loaded before the warm-up if it exists, written after it (profiling runs then skip the tuner's candidate launches)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--model", default="sd21-base")
     ap.add_argument("--vae", default="sd")
@@ -208,6 +210,9 @@ def main():
             dist.init_process_group("nccl", device_id=device)
     from freefine_amd import _lib
     _lib.load()   # no fallback: fail loudly if the HIP extension is missing
+    from freefine_amd import ops as _ops
+    if args.tune_file:
+        _ops.tune_table_load(args.tune_file)
     model = build_model(args, device, rank, world)
 
     def barrier():
@@ -226,6 +231,9 @@ def main():
             for i in range(max(args.warmup, 1 if args.concurrent > 1 else 0)):
                 edit_once(m, args, rank * 1000 + 10 * j + i)
         st.synchronize()
+
+    if args.tune_file and rank == 0:
+        _ops.tune_table_save(args.tune_file)
 
     def worker(j):
         torch.cuda.set_device(device)

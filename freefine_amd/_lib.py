@@ -72,7 +72,11 @@ SYMBOLS = {
     "ffn_device_info": (_i, [_i, C.c_char_p, _i]),
     "ffn_igemm": (_i, [_vp, _i, C.POINTER(IgemmDesc)]),
     "ffn_attn": (_i, [_vp, _i, C.POINTER(AttnDesc)]),
+    "ffn_attn_kernel_name": (_i, [_i, C.POINTER(AttnDesc), C.c_char_p, _i]),
     "ffn_igemm_tune": (_i, [_vp, _i, C.POINTER(IgemmDesc)]),
+    "ffn_igemm_tune_entry_ints": (_i, []),
+    "ffn_igemm_tune_export": (_i, [C.POINTER(C.c_int), _i]),
+    "ffn_igemm_tune_import": (_i, [C.POINTER(C.c_int), _i]),
     "ffn_igemm_num_configs": (_i, []),
     "ffn_igemm_force_config": (_i, [_i]),
     "ffn_igemm_variant": (_i, [C.POINTER(IgemmDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

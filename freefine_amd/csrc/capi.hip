@@ -261,9 +261,9 @@ static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn) {
     if (d.rowbias && d.rows_per_batch < 128) return false;      // a wave's rows (bm / 2) may straddle two images, not three
     long a_bytes;
     if (d.conv) {
-        if (d.Cin % 64 != 0 || d.upsample || d.K != 9 * d.Cin || d.Cin / 64 * 9 * (d.Cin / 64) >= 65536) return false;
+        if (d.Cin % 64 != 0 || d.K != 9 * d.Cin || d.Cin / 64 * 9 * (d.Cin / 64) >= 65536) return false;
         a_bytes = (long)(d.M / (d.Hout * d.Wout)) * d.Hin * d.Win * d.Cin * 2;
-        if (d.Hin + 2 >= 32768 || d.Win + 2 >= 32768) return false;
+        if (2 * d.Hin + 2 >= 32768 || 2 * d.Win + 2 >= 32768) return false;
     } else {
         a_bytes = (long)d.M * d.lda * 2;
     }
@@ -535,6 +535,39 @@ static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
                 d.K, d.flags, kCfg[best.cfg].bm, kCfg[best.cfg].bn, best.splitk, best_ms * 1e3f / reps, nc);
     return launch_bf16_cfg<AMODE>(s, d, best);       // the output now holds the winner's result
 }
+// ---- the tuned table as data: export / import (persist it across processes, broadcast rank 0's table so that every rank of a
+// sharded run launches the same configurations -- bf16 results then are bit-identical across ranks)
+static constexpr int kTuneEntryInts = (int)(sizeof(TuneKey) / sizeof(int)) + 2;
+extern "C" int ffn_igemm_tune_entry_ints(void) { return kTuneEntryInts; }
+extern "C" int ffn_igemm_tune_export(int* buf, int max_entries) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    int n = 0;
+    for (const auto& kv : g_tuned) {
+        if (buf && n < max_entries) {
+            int* e = buf + (long)n * kTuneEntryInts;
+            memcpy(e, &kv.first, sizeof(TuneKey));
+            e[kTuneEntryInts - 2] = kv.second.cfg;
+            e[kTuneEntryInts - 1] = kv.second.splitk;
+        }
+        ++n;
+    }
+    return n;       // number of entries in the table (may exceed max_entries: call again with a larger buffer)
+}
+extern "C" int ffn_igemm_tune_import(const int* buf, int n_entries) {
+    REQUIRE(buf || n_entries == 0, "igemm_tune_import: null buffer");
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    int n = 0;
+    for (int i = 0; i < n_entries; ++i) {
+        const int* e = buf + (long)i * kTuneEntryInts;
+        TuneKey k;
+        memcpy(&k, e, sizeof(TuneKey));
+        const IgChoice ch{e[kTuneEntryInts - 2], e[kTuneEntryInts - 1]};
+        if (ch.cfg < 0 || ch.cfg >= CFG_COUNT || ch.splitk < 1) continue;       // a table from another build: ignore what does not fit
+        g_tuned[k] = ch;
+        ++n;
+    }
+    return n;
+}
 static bool tuned_lookup(const ffn_igemm_desc& d, IgChoice* ch) {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = g_tuned.find(tune_key(d));
@@ -644,6 +677,36 @@ static int launch_attn(hipStream_t s, const ffn_attn_desc& d) {
     LAUNCH(kern, grid, dim3(256), lds, s, d);
     return check_launch("attn");
 }
+// bf16 launches: whether some active entry carries a key mask (-> the kernel variant with the mask-on-MFMA tile) and whether the
+// launch runs on the ping-pong schedule (attention_pp.h): d = 64, whole 64-key tiles, at least half a 256-query workgroup of queries,
+// no degenerate uniform-softmax entries (those need the generic tile)
+static void attn_bf16_choice(const ffn_attn_desc& d, bool* masks, bool* pp) {
+    bool m = false, uniform = false;
+    for (int pi = 0; pi < d.npass; ++pi)
+        for (int b = 0; b < d.Bo; ++b) {
+            const ffn_attn_entry& e = d.e[pi * FFN_ATT_MAXB + b];
+            if (e.w_const == 0.f && e.w_slope == 0.f) continue;
+            m |= e.kmask != nullptr;
+            uniform |= e.kmask != nullptr && (e.flags & (FFN_ATT_UNIFORM_SEL1 | FFN_ATT_UNIFORM_SEL0));
+        }
+    static const bool pp_on = [] { const char* e = getenv("FFN_ATTN_PP"); return !(e && atoi(e) == 0); }();
+    *masks = m;
+    *pp = pp_on && d.D == 64 && d.Sk % 64 == 0 && d.S >= 128 && !uniform;
+}
+extern "C" int ffn_attn_kernel_name(int dtype, const ffn_attn_desc* d, char* buf, int len) {
+    REQUIRE(d && buf && len > 0, "attn_kernel_name: null argument");
+    int dp = 0, qf = 0;
+    ffn_attn_variant(dtype, d->D, &dp, &qf);
+    if (dtype == FFN_F32) {
+        snprintf(buf, len, "void attn_kernel<float, %d, %d, %d, 1, true>(ffn_attn_desc)", dp, qf, dp == 160 ? 32 : 64);
+        return FFN_OK;
+    }
+    bool masks, pp;
+    attn_bf16_choice(*d, &masks, &pp);
+    if (pp) snprintf(buf, len, "void attn_pp_kernel<%s>(ffn_attn_desc)", masks ? "true" : "false");
+    else snprintf(buf, len, "void attn_kernel<bf16, %d, %d, 64, %d, %s>(ffn_attn_desc)", dp, qf, dp == 64 ? 2 : 1, masks ? "true" : "false");
+    return FFN_OK;
+}
 extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
     REQUIRE(d, "attn: null descriptor");
     REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "attn: bad dtype %d", dtype);
@@ -664,18 +727,9 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
         if (D <= 80) return launch_attn<float, 80, 2>(s, *d);
         if (D <= 160) return launch_attn<float, 160, 1, 32>(s, *d);
     } else {
-        bool masks = false;      // any (pass, row) entry with a key mask -> the kernel variant with the mask-on-MFMA tile
-        bool uniform = false;    // ... with a degenerate uniform-softmax query set (generic tile only)
-        for (int pi = 0; pi < d->npass; ++pi)
-            for (int b = 0; b < d->Bo; ++b) {
-                const ffn_attn_entry& e = d->e[pi * FFN_ATT_MAXB + b];
-                if (e.w_const == 0.f && e.w_slope == 0.f) continue;
-                masks |= e.kmask != nullptr;
-                uniform |= e.kmask != nullptr && (e.flags & (FFN_ATT_UNIFORM_SEL1 | FFN_ATT_UNIFORM_SEL0));
-            }
-        // the ping-pong schedule (attention_pp.h): d = 64, whole 64-key tiles, at least one 256-query workgroup worth of queries
-        static const bool pp_on = [] { const char* e = getenv("FFN_ATTN_PP"); return !(e && atoi(e) == 0); }();
-        if (pp_on && D == 64 && d->Sk % 64 == 0 && d->S >= 128 && !uniform) {
+        bool masks, pp;
+        attn_bf16_choice(*d, &masks, &pp);
+        if (pp) {
             constexpr int lds = 4 * 8192 + 4 * 8192 + 4 * 256 + 8 * 4 * 2 * 64 * 16;
             dim3 grid(((d->S + 255) / 256) * d->heads * d->Bo);
             int rc;

@@ -129,6 +129,23 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     const float cdf = 0.5f + copysignf(0.5f * erf_abs, x);
     return x * cdf;
 }
+// Two GELUs at once for the GEGLU epilogue of the bf16 GEMMs (the result is rounded to bf16, 2^-9): erf by Abramowitz-Stegun
+// 7.1.25 (three coefficients, |error| <= 2.5e-5) on float2 values, so that everything but the two v_rcp / v_exp runs as packed f32
+// instructions (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of work per issue slot -- the epilogue has no MFMA beside it to disturb).
+// gelu_erf_fast cost ~17 instructions per value; the K = 320 feed-forward GEMM spent as long in its GEGLU epilogue as in its K loop.
+__device__ __forceinline__ f32x2_t gelu_erf_fast2(f32x2_t x) {
+    const f32x2_t z = f32x2_t{fabsf(x[0]), fabsf(x[1])} * 0.70710678118654752440f;
+    f32x2_t t = z * 0.47047f + 1.0f;
+    t = f32x2_t{__builtin_amdgcn_rcpf(t[0]), __builtin_amdgcn_rcpf(t[1])};
+    f32x2_t poly = t * 0.7478556f + (-0.0958798f);
+    poly = poly * t + 0.3480242f;
+    poly = poly * t;
+    const f32x2_t zz = z * z * (-1.44269504088896340736f);
+    const f32x2_t e = f32x2_t{__builtin_amdgcn_exp2f(zz[0]), __builtin_amdgcn_exp2f(zz[1])};
+    const f32x2_t half_erf = poly * e * (-0.5f) + 0.5f;                     // 0.5 * erf(|x| / sqrt 2)
+    const f32x2_t cdf = f32x2_t{copysignf(half_erf[0], x[0]), copysignf(half_erf[1], x[1])} + 0.5f;
+    return x * cdf;
+}
 template <typename T>
 __device__ __forceinline__ float gelu_for(float x) {
     if constexpr (sizeof(T) == 2) return gelu_erf_fast(x);

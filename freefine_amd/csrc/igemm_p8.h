@@ -41,7 +41,7 @@
 // on gfx950: tools/native/probe_bufload_lds.hip), so there is no zero page and no select.
 //
 // Restrictions (checked by the launcher, capi.hip): bf16; K % 64 == 0 and K >= 128 (conv: Cin % 64 == 0); N % BN == 0; alpha == 1;
-// flags subset of {GEGLU (BN = 256)}; no upsampling conv; rowbias only with rows_per_batch >= 128; every operand < 2 GiB.
+// flags subset of {GEGLU (BN = 256)}; rowbias only with rows_per_batch >= 128; every operand < 2 GiB.
 #pragma once
 #include <type_traits>
 #include "igemm.h"
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
                 const int hw = p.Hout * p.Wout;
                 const int b = m / hw, rem = m - b * hw;
                 const int yo = rem / p.Wout, xo = rem - yo * p.Wout;
-                const int y0 = yo * p.stride - p.pad, x0 = xo * p.stride - p.pad;
-                a_off[i] = ((b * p.Hin + y0) * p.Win + x0) * (p.Cin * 2) + csrc * 16;
+                const int y0 = yo * p.stride - p.pad, x0 = xo * p.stride - p.pad;       // in (nearest-2x upsampled) input coordinates
+                a_off[i] = ((b * p.Hin + (y0 >> p.upsample)) * p.Win + (x0 >> p.upsample)) * (p.Cin * 2) + csrc * 16;
                 a_yx[i] = m < p.M ? ((y0 << 16) | (x0 & 0xffff)) : (int)0x80008000;       // rows past M: every tap out of the image
             }
         }
@@ -161,9 +161,15 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
     auto issue_a = [&](int i, int buf) {
         int voff = a_off[i];
         if (AMODE != AMODE_DENSE) {
-            const int yy = (a_yx[i] >> 16) + tap_ky, xx = (int)(short)(a_yx[i] & 0xffff) + tap_kx;
-            const bool inb = (unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
-            voff = inb ? voff + tap_off : OOB;
+            const int y0 = a_yx[i] >> 16, x0 = (int)(short)(a_yx[i] & 0xffff);
+            const int yy = y0 + tap_ky, xx = x0 + tap_kx;
+            const bool inb = (unsigned)yy < (unsigned)(p.Hin << p.upsample) && (unsigned)xx < (unsigned)(p.Win << p.upsample);
+            int toff = tap_off;
+            if (p.upsample) {     // fused nearest-2x upsample: source pixel (yy >> 1, xx >> 1); the step from tap (0,0) depends on the parity of y0 / x0
+                const int dy = (tap_ky + (y0 & 1)) >> 1, dx = (tap_kx + (x0 & 1)) >> 1;
+                toff = (dy * p.Win + dx) * (p.Cin * 2);
+            }
+            voff = inb ? voff + toff : OOB;
         }
         if (PP_ABL != 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)(smem + buf * BUF + apiece[i] * 1024), 16, voff, ka, 0, 0);
     };
@@ -276,9 +282,11 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
             if constexpr (GEGLU) {
 #pragma unroll
                 for (int j = 0; j + 1 < FN; j += 2) {
+                    const f32x2_t g01 = gelu_erf_fast2(f32x2_t{acc[i][j + 1][0], acc[i][j + 1][1]}) * f32x2_t{acc[i][j][0], acc[i][j][1]};
+                    const f32x2_t g23 = gelu_erf_fast2(f32x2_t{acc[i][j + 1][2], acc[i][j + 1][3]}) * f32x2_t{acc[i][j][2], acc[i][j][3]};
                     u32x2 w;
-                    w[0] = pack_bf16x2(acc[i][j][0] * gelu_for<T>(acc[i][j + 1][0]), acc[i][j][1] * gelu_for<T>(acc[i][j + 1][1]));
-                    w[1] = pack_bf16x2(acc[i][j][2] * gelu_for<T>(acc[i][j + 1][2]), acc[i][j][3] * gelu_for<T>(acc[i][j + 1][3]));
+                    w[0] = pack_bf16x2(g01[0], g01[1]);
+                    w[1] = pack_bf16x2(g23[0], g23[1]);
                     __builtin_amdgcn_raw_buffer_store_b64(w, rsrcO, voff, ((m0 + i * 16) * p.ldo + n0 / 2 + (j / 2) * 16) * 2, 0);
                 }
             } else {

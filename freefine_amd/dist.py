@@ -68,3 +68,15 @@ def gather_results(local_results):
                 seen.add(k)
             merged.append(item)
     return merged
+
+
+def sync_tune_table(src=0):
+    """every rank adopts rank `src`'s igemm tuning table (freefine_amd.ops.tune_table_*): identical tile / split-K choices on all
+    ranks, hence bit-identical bf16 results across the ranks of a sharded run (the tuner picks by timing, which may differ per GPU).
+    Works on any backend: the table is a small int32 tensor shipped with broadcast_object_list."""
+    from . import ops
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    box = [ops.tune_table_export() if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return ops.tune_table_import(box[0]) if dist.get_rank() != src else box[0].shape[0]

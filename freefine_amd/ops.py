@@ -73,13 +73,6 @@ def _timed(name, flops, nbytes, fn):
     return rc
 
 
-def _attn_name(q, dp, qf, Dh, masks=True):
-    kt = 32 if (q.dtype == torch.float32 and dp == 160) else 64
-    occ = 2 if (q.dtype == torch.bfloat16 and dp == 64) else 1
-    mk = "true" if (masks or q.dtype == torch.float32) else "false"      # bf16 launches without key masks run the leaner variant
-    return f"void attn_kernel<{_tname(q)}, {dp}, {qf}, {kt}, {occ}, {mk}>(ffn_attn_desc)"
-
-
 def _tname(t):
     return "float" if t.dtype == torch.float32 else "bf16"
 
@@ -282,10 +275,9 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
             L.check(lib.ffn_attn(_stream(), _dt(q), CT.byref(d)), "ffn_attn")
         else:
             nterms = sum(1 for rows in passes for sp in rows[b0:b0 + nb] if sp is not None and (sp.w_const != 0.0 or sp.w_slope != 0.0))
-            dp, qf = CT.c_int(), CT.c_int()
-            lib.ffn_attn_variant(_dt(q), Dh, CT.byref(dp), CT.byref(qf))
-            masks = any(sp is not None and sp.kmask is not None for rows in passes for sp in rows[b0:b0 + nb])
-            L.check(_timed(_attn_name(q, dp.value, qf.value, Dh, masks), 4.0 * nterms * S * Sk * Cq,
+            nbuf = CT.create_string_buffer(160)
+            lib.ffn_attn_kernel_name(_dt(q), CT.byref(d), nbuf, 160)
+            L.check(_timed(nbuf.value.decode(), 4.0 * nterms * S * Sk * Cq,
                            esz * nterms * (S * Cq + 2 * Sk * Cq) + esz * nb * S * Cq,
                            lambda: lib.ffn_attn(_stream(), _dt(q), CT.byref(d))), "ffn_attn")
     return out
@@ -467,3 +459,36 @@ def nhwc_to_image(src, H, W, out=None):
         out = torch.empty(B, 3, H, W, dtype=torch.float32, device=src.device)
     L.check(lib.ffn_nhwc_to_image(_stream(), _dt(src), src.data_ptr(), out.data_ptr(), B, HW, ld), "ffn_nhwc_to_image")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the igemm tuner's table as data (persist across processes / broadcast across ranks)
+# ---------------------------------------------------------------------------------------------------------------
+def tune_table_export():
+    """int32 tensor [n, entry_ints] of the bf16 igemm configurations tuned so far in this process."""
+    lib = L.load()
+    w = lib.ffn_igemm_tune_entry_ints()
+    n = lib.ffn_igemm_tune_export(None, 0)
+    buf = (CT.c_int * max(1, n * w))()
+    n = min(n, lib.ffn_igemm_tune_export(buf, n))
+    return torch.tensor(list(buf[:n * w]), dtype=torch.int32).reshape(n, w)
+
+
+def tune_table_import(table):
+    """merge a table produced by tune_table_export (another process, another rank); returns the number of entries taken."""
+    lib = L.load()
+    table = table.to(torch.int32).contiguous().cpu()
+    w = lib.ffn_igemm_tune_entry_ints()
+    if table.numel() == 0 or table.shape[1] != w:
+        return 0
+    buf = (CT.c_int * table.numel())(*table.flatten().tolist())
+    return lib.ffn_igemm_tune_import(buf, table.shape[0])
+
+
+def tune_table_save(path):
+    torch.save(tune_table_export(), path)
+
+
+def tune_table_load(path):
+    import os
+    return tune_table_import(torch.load(path)) if os.path.exists(path) else 0

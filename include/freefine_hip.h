@@ -72,6 +72,13 @@ int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
  * (f32 always uses it).  Testing hooks: the number of bf16 configurations, and forcing one (-1 = off; returns the previous value). */
 /* explicit warm-up entry point: tunes (or looks up) the configuration for `d` now, exactly as the first ffn_igemm call would */
 int ffn_igemm_tune(void* stream, int dtype, const ffn_igemm_desc* d);
+/* the tuned table as data: entries of ffn_igemm_tune_entry_ints() ints (problem key, configuration, K split).  export returns the
+ * number of entries in the table (copies at most max_entries); import merges entries (unknown configurations are skipped) and returns
+ * how many it took.  Use: persist the table across processes, or broadcast rank 0's table in a multi-GPU run so that every rank
+ * launches identical configurations. */
+int ffn_igemm_tune_entry_ints(void);
+int ffn_igemm_tune_export(int* buf, int max_entries);
+int ffn_igemm_tune_import(const int* buf, int n_entries);
 int ffn_igemm_num_configs(void);
 int ffn_igemm_force_config(int cfg);
 /* which tile (BM x BN) ffn_igemm dispatches for this problem -- lets a profiler name the kernel instantiation */
@@ -112,6 +119,8 @@ typedef struct ffn_attn_desc {
 int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d);
 /* padded head dim / query fragments per wave of the instantiation ffn_attn dispatches for head dim D */
 int ffn_attn_variant(int dtype, int D, int* dp, int* qf);
+/* the kernel instantiation ffn_attn launches for this problem, spelled like rocprofv3's kernel trace */
+int ffn_attn_kernel_name(int dtype, const ffn_attn_desc* d, char* buf, int len);
 
 /* ---- normalisation ------------------------------------------------------------------------------------------- */
 /* GroupNorm statistics -> per-(batch,channel) scale/shift (fp32).  partial_ws: >= B*nchunk*2*C floats where

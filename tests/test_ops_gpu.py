@@ -436,6 +436,20 @@ def test_every_bf16_igemm_configuration(gpu):
                 ref = torch.nn.functional.conv2d(xr, w.double().cpu(), b.double().cpu(), padding=1) + rb.double().cpu()[:, :, None, None]
                 ref = ref.permute(0, 2, 3, 1).reshape(B, H * W, Cout) + r.double().cpu()
                 assert relerr(out, ref) < tol(dt), (cfg, "conv-pp-shapes", H, W, Cout)
+            # ping-pong kernel: fused nearest-2x upsample, stride 2 (pad 1, and the VAE encoder's pad-right/bottom-only form)
+            for (B, H, W, Cin, Cout, stride, pad, up) in [(2, 16, 16, 128, 320, 1, 1, True), (2, 32, 32, 64, 320, 2, 1, False), (3, 32, 32, 64, 256, 2, 0, False)]:
+                x, w = rnd((B, Cin, H, W), dt, gpu, g), rnd((Cout, Cin, 3, 3), dt, gpu, g, (9 * Cin) ** -0.5)
+                b = rnd((Cout,), torch.float32, gpu, g)
+                xin = x.double().cpu()
+                if up:
+                    xin = torch.nn.functional.interpolate(xin, scale_factor=2.0, mode="nearest")
+                if pad == 0:
+                    xin = torch.nn.functional.pad(xin, (0, 1, 0, 1))
+                ref = torch.nn.functional.conv2d(xin, w.double().cpu(), b.double().cpu(), stride=stride, padding=pad)
+                Ho, Wo = ref.shape[-2:]
+                out = ops.conv3x3(x.permute(0, 2, 3, 1).reshape(B, H * W, Cin).contiguous(), ops.pack_conv3x3(w, dt), b, B, H, W, Cin, stride=stride,
+                                  pad=pad, upsample=up, Hout=Ho, Wout=Wo)
+                assert relerr(out, ref.permute(0, 2, 3, 1).reshape(B, Ho * Wo, Cout)) < tol(dt), (cfg, "conv-pp-variants", stride, pad, up)
             # shapes the halo conv kernel accepts: tiles of whole image rows (32x32, 16x16) and pieces of one wide row (4x256)
             for (B, H, W, Cin, Cout) in [(2, 32, 32, 128, 320), (3, 16, 16, 192, 256), (1, 4, 256, 64, 128)]:
                 x, w = rnd((B, H * W, Cin), dt, gpu, g), rnd((Cout, Cin, 3, 3), dt, gpu, g, (9 * Cin) ** -0.5)
