@@ -25,7 +25,7 @@ from .scheduler import DDIMScheduler
 from .text import ByteTokenizer, SyntheticTextEncoder
 from .unet import HipUNet
 from .vae import HipVAE
-from .weights import load_safetensors_dir, synthetic_state, unet_param_shapes, vae_param_shapes
+from .weights import load_safetensors_dir, normalize_state_dict, synthetic_state, unet_param_shapes, vae_param_shapes, validate_state_dict
 
 
 def seed_everything(seed):
@@ -97,6 +97,9 @@ class FreeFinePipeline:
 
     @classmethod
     def from_state(cls, ucfg, ustate, vcfg, vstate, tokenizer, text_encoder, scheduler=None, dtype=torch.float32, device="cuda:0"):
+        ustate, vstate = normalize_state_dict(ustate), normalize_state_dict(vstate)      # hub checkpoints: legacy VAE attention names
+        validate_state_dict(ustate, unet_param_shapes(ucfg), "unet")
+        validate_state_dict(vstate, vae_param_shapes(vcfg), "vae")
         unet = HipUNet(ucfg, ustate, dtype=dtype, device=device)
         vae = HipVAE(vcfg, vstate, dtype=dtype, device=device)
         return cls(unet, vae, tokenizer, text_encoder, scheduler or DDIMScheduler(), device)

@@ -155,6 +155,37 @@ def synthetic_state(shapes, seed=0):
     return out
 
 
+# the VAE mid-block attention of the SD-1.x / 2.x checkpoints on the hub still carries the pre-0.14 diffusers parameter names (1x1
+# convolutions stored 4-D); diffusers renames them at load time (AttentionBlock -> Attention deprecation path), so do we
+_LEGACY_VAE_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+
+def normalize_state_dict(state):
+    """legacy -> current diffusers key names (VAE attention), 1x1-conv weights of Linear-shaped layers flattened to 2-D."""
+    out = {}
+    for k, v in state.items():
+        parts = k.split(".")
+        if len(parts) >= 2 and ".attentions." in k and parts[-2] in _LEGACY_VAE_ATTN:
+            parts[-2] = _LEGACY_VAE_ATTN[parts[-2]]
+            k = ".".join(parts)
+            if v.ndim == 4 and v.shape[2] == v.shape[3] == 1:
+                v = v.reshape(v.shape[0], v.shape[1])
+        out[k] = v
+    return out
+
+
+def validate_state_dict(state, shapes, what):
+    """fail with a readable message (not a KeyError deep inside the packer) when a checkpoint does not match the topology."""
+    missing = sorted(set(shapes) - set(state))
+    if missing:
+        raise ValueError(f"{what}: {len(missing)} parameter(s) missing from the checkpoint, e.g. {missing[:4]} "
+                         f"(have {len(state)} tensors; unexpected: {sorted(set(state) - set(shapes))[:4]})")
+    for k, shp in shapes.items():
+        got = tuple(state[k].shape)
+        if got != tuple(shp) and not (len(got) == 4 and got[2:] == (1, 1) and got[:2] == tuple(shp)):
+            raise ValueError(f"{what}: parameter {k} has shape {got}, expected {tuple(shp)}")
+
+
 def load_safetensors_dir(path, sub):
     """path/sub/{config.json, diffusion_pytorch_model.safetensors}"""
     from safetensors.torch import load_file
@@ -164,5 +195,5 @@ def load_safetensors_dir(path, sub):
     for fn in ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors", "model.safetensors"):
         fp = os.path.join(folder, fn)
         if os.path.exists(fp):
-            return cfg, {k: v.float() for k, v in load_file(fp).items()}
+            return cfg, normalize_state_dict({k: v.float() for k, v in load_file(fp).items()})
     raise FileNotFoundError(f"no safetensors under {folder}")

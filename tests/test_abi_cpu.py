@@ -27,6 +27,26 @@ def test_invalid_arguments_are_reported_not_crashed():
     assert lib.ffn_attn(None, 7, ctypes.byref(a)) == -22
 
 
+def test_tune_table_roundtrip_and_rejects_foreign_entries(tmp_path):
+    """ffn_igemm_tune_export / _import: the tuned (problem -> configuration) table as data; entries naming a configuration this build
+    does not have are skipped (a table written by another build must not crash or mis-launch)."""
+    import torch
+    from freefine_amd import _lib, ops
+    lib = _lib.load()
+    w = lib.ffn_igemm_tune_entry_ints()
+    before = ops.tune_table_export()
+    t = torch.zeros(3, w, dtype=torch.int32)
+    t[:, 0] = torch.tensor([111, 222, 333]); t[:, 1] = 64; t[:, 2] = 128
+    t[:, -2] = torch.tensor([2, lib.ffn_igemm_num_configs() + 5, 0]); t[:, -1] = torch.tensor([1, 1, 0])      # entry 1: unknown cfg; entry 2: split 0
+    assert ops.tune_table_import(t) == 1
+    after = ops.tune_table_export()
+    assert after.shape[0] == before.shape[0] + 1 and 111 in after[:, 0].tolist() and 222 not in after[:, 0].tolist()
+    f = tmp_path / "tune.pt"
+    ops.tune_table_save(str(f))
+    assert ops.tune_table_load(str(f)) == after.shape[0]
+    assert ops.tune_table_load(str(tmp_path / "missing.pt")) == 0
+
+
 def test_controller_plan_tables_host_logic():
     """Attention_Modulator.plan: dispatch + counters mirror the reference protocol (no GPU needed: vectors on CPU)."""
     import torch
@@ -46,3 +66,32 @@ def test_controller_plan_tables_host_logic():
     assert branches[0] == "plain" and branches[1] == "cross_local"
     assert [b for b in branches if b.startswith("tca")] == ["tca:tca"] * 6          # blocks 10..15 only
     assert branches[14] == "plain"                                                     # first 'up' self-attn is block 7
+
+
+def test_legacy_vae_attention_keys_are_renamed_and_bad_checkpoints_fail_clearly():
+    """SD-1.5 / SD-2.1 VAE safetensors on the hub name the mid-block attention query/key/value/proj_attn (4-D 1x1 conv weights);
+    the loader maps them to to_q/to_k/to_v/to_out.0 like diffusers does, and a checkpoint that does not fit the topology is
+    rejected with a message naming the missing parameters."""
+    import pytest
+    import torch
+    from freefine_amd.config import VAEConfig
+    from freefine_amd.weights import normalize_state_dict, synthetic_state, vae_param_shapes, validate_state_dict
+    shapes = vae_param_shapes(VAEConfig.preset("tiny"))
+    st = synthetic_state(shapes, 3)
+    legacy = {}
+    ren = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_attn"}
+    for k, v in st.items():
+        for new, old in ren.items():
+            if f".attentions.0.{new}." in k:
+                k = k.replace(f".{new}.", f".{old}.")
+                if v.ndim == 2:
+                    v = v[:, :, None, None]
+        legacy[k] = v
+    assert any(".query.weight" in k for k in legacy) and not any(".to_q." in k for k in legacy)
+    fixed = normalize_state_dict(legacy)
+    assert set(fixed) == set(st) and all(torch.equal(fixed[k], st[k]) for k in st)
+    validate_state_dict(fixed, shapes, "vae")
+    broken = dict(fixed)
+    broken.pop("decoder.conv_out.bias")
+    with pytest.raises(ValueError, match="decoder.conv_out.bias"):
+        validate_state_dict(broken, shapes, "vae")

@@ -23,6 +23,16 @@ n = 7
 mine = FD.shard_indices(n, rank, world)
 res = FD.gather_results([{"key": i, "rank": rank, "val": i * i} for i in mine])
 assert sorted(r["key"] for r in res) == list(range(n)), res
+# the igemm tuning table travels from rank 0 to everyone (identical tile / split-K choices on all ranks)
+from freefine_amd import ops
+w = ops.tune_table_export().shape[1]
+if rank == 0:
+    t = torch.zeros(3, w, dtype=torch.int32)
+    t[:, 0] = torch.tensor([4096, 8192, 98304]); t[:, 1] = 320; t[:, 2] = 320; t[:, -2] = torch.tensor([1, 6, 13]); t[:, -1] = 1
+    assert ops.tune_table_import(t) == 3
+n_tab = FD.sync_tune_table()
+tab = ops.tune_table_export()
+assert tab.shape[0] == 3 and sorted(tab[:, 0].tolist()) == [4096, 8192, 98304] and sorted(tab[:, -2].tolist()) == [1, 6, 13], tab
 if rank == 0:
     print("DIST_OK", len(res))
 dist.destroy_process_group()

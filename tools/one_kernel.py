@@ -1,4 +1,4 @@
-"""Run ONE kernel shape repeatedly (for rocprofv3 --pmc passes).  python tools/one_kernel.py conv 64 320 320 | gemm M K N | attn S C heads passes"""
+"""Run ONE kernel shape repeatedly (for rocprofv3 --pmc passes).  python tools/one_kernel.py conv 64 320 320 | gemm M K N | geglu M K N | attn S C heads passes"""
 import os
 import sys
 
@@ -19,6 +19,12 @@ if kind == "conv":
     w = ops.pack_conv3x3(rnd(cout, cin, 3, 3, scale=(9 * cin) ** -0.5), dt)
     b = torch.zeros(cout, device=dev)
     fn = lambda: ops.conv3x3(x, w, b, B, hw, hw, cin)
+elif kind == "geglu":
+    M, K, N = map(int, sys.argv[2:5])       # N = packed hidden | gate columns
+    x = rnd(M, K)
+    wp, bp = ops.pack_geglu(rnd(N, K, scale=K ** -0.5), torch.zeros(N, device=dev), dt)
+    out = torch.empty(M, N // 2, dtype=dt, device=dev)
+    fn = lambda: ops.linear(x, wp, bp, K=K, geglu=True, out=out)
 elif kind == "gemm":
     M, K, N = map(int, sys.argv[2:5])
     x = rnd(M, K)
