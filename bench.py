@@ -119,11 +119,12 @@ def roofline_leg(model, args):
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/pmc.sh; FETCH_SIZE x2 per the gfx950
     # correction of MI355X_MICROARCH.md, WRITE_SIZE), recorded per round under profiles/: reported only if it is the same kernel
     traffic, traffic_note = None, None
-    pmc = os.path.join(ROOT, "profiles", "r1_pmc_dominant.json")
-    if os.path.exists(pmc):
-        rec = json.load(open(pmc))
-        if rec.get("kernel") == name:
-            traffic, traffic_note = rec["traffic_bytes_per_launch"], rec.get("note")
+    import glob
+    for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dominant.json")), reverse=True):     # newest round first
+        recs = json.load(open(pmc))
+        for rec in (recs if isinstance(recs, list) else [recs]):
+            if traffic is None and rec.get("kernel") == name:
+                traffic, traffic_note = rec["traffic_bytes_per_launch"], rec.get("note")
     out = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
                traffic=traffic, launches=d["calls"], avg_launch_us=round(avg_ms * 1e3, 2),
                share_of_timed_kernels=round(d["total_ms"] / total_ms, 3))

@@ -126,6 +126,13 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
     // The position along K is a pure SCALAR function of the loader's K-tile counter (no loop-carried tap state: with `if (ka >= Cin)`
     // style updates hipcc moved the whole tap state into VGPRs and put a v_readfirstlane + hazard nops, or a waterfall loop, in
     // front of every load).  cpt = 64-channel chunks per tap; tap = l_kt / cpt by a 16-bit reciprocal (exact for l_kt * cpt < 65536).
+    // K order of a convolution: tap-major (all 64-channel chunks of tap 0, then tap 1, ...: every activation row and every weight row
+    // is streamed front to back).  The nine taps re-read the activations, and the per-XCD footprint between two taps (32 CUs x 256
+    // pixels x Cin x 2 B = 5.2 MB at Cin = 320) exceeds the 4 MiB L2: the dominant launch fetches 1.15 GB for 127 MB of activations
+    // (profiles/r2_pmc_*; 379 MB with the 192-row tile).  Two walks that keep the re-reads in L2 were built and measured -- chunk-major
+    // (the nine taps of a chunk back to back) and (ky, chunk, kx) -- and both run 5-13 % SLOWER (310 / 313 vs 289 us at M = 196608,
+    // Cin = 320; 373 vs 339 us at 32x32 x 640): the launch is not bound by where its lines come from, and the strided walks lose more
+    // (requests to lines still in flight, weight rows no longer streamed) than the L2 hits return.
     const int cpt = AMODE == AMODE_DENSE ? 1 : p.Cin / 64;
     const int cpt_rcp = (65536 + cpt - 1) / cpt;
     int ka = 0, tap_ky = 0, tap_kx = 0, tap_off = 0;  // of K tile l_kt; set by k_position()

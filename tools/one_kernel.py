@@ -36,7 +36,7 @@ else:
     km = (torch.rand(S, generator=g) > 0.7).to(torch.uint8).to(dev)
     qs = (torch.rand(S, generator=g) > 0.5).to(torch.uint8).to(dev)
     cg = torch.tensor([0.5], device=dev)
-    P = None if passes == 1 else [[ops.AttnEntrySpec(b, [1, 1, 3, 3][b], 0.0, 1.0, kmask=km, qsel=qs, flags=1) for b in range(B)],
+    P = None if passes == 1 else [[ops.AttnEntrySpec(b, b | 1, 0.0, 1.0, kmask=km, qsel=qs, flags=1) for b in range(B)],
                                   [ops.AttnEntrySpec(b, b, 1.0, -1.0) for b in range(B)]]
     fn = lambda: ops.attention(q, k, vt, heads, (C // heads) ** -0.5, P, w_dev=cg)
 for _ in range(10):
