@@ -253,12 +253,16 @@ struct IgChoice { int cfg, splitk; };
 static bool is_halo_cfg(int cfg) { return cfg == CFG_H_128x320 || cfg == CFG_H_256x128 || cfg == CFG_H_256x256 || cfg == CFG_H_128x128; }
 static bool is_pp_cfg(int cfg) { return cfg >= CFG_PP_256x320 && cfg <= CFG_PP_192x256; }
 // whether the ping-pong kernel (igemm_p8.h) handles this problem on a bm x bn tile: its restrictions are listed in that header
-static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn) {
+static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn, int splitk = 1) {
     const long lim = (1l << 31) - 4096;
-    if (d.K % 64 != 0 || d.K < 128 || d.N % bn != 0 || d.alpha != 1.0f || d.M < bm) return false;
-    if (d.flags & ~FFN_IG_GEGLU) return false;
-    if ((d.flags & FFN_IG_GEGLU) && bn != 256) return false;
-    if (d.rowbias && d.rows_per_batch < 128) return false;      // a wave's rows (bm / 2) may straddle two images, not three
+    if (d.K % 64 != 0 || d.K < 128 || d.N % bn != 0 || d.M < bm) return false;
+    if (splitk > 1) {       // split-K: raw fp32 slabs + igemm_splitk_reduce_kernel (which applies every plain epilogue option)
+        if (!can_split(d) || (d.K / 64) % splitk != 0 || (long)splitk * d.M * d.N * 4 > d.ws_bytes || (long)splitk * d.M * d.N * 4 >= lim) return false;
+    } else {
+        if (d.alpha != 1.0f || (d.flags & ~FFN_IG_GEGLU)) return false;
+        if ((d.flags & FFN_IG_GEGLU) && bn != 256) return false;
+        if (d.rowbias && d.rows_per_batch < 128) return false;      // a wave's rows (bm / 2) may straddle two images, not three
+    }
     long a_bytes;
     if (d.conv) {
         if (d.Cin % 64 != 0 || d.K != 9 * d.Cin || d.Cin / 64 * 9 * (d.Cin / 64) >= 65536) return false;
@@ -318,16 +322,16 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
         case CFG_PP_256x256:
         case CFG_PP_192x320:
         case CFG_PP_192x256: {
-            if (!pp_ok(d, c.bm, c.bn) || ch.splitk != 1) return fail(FFN_EINVAL, "igemm: ping-pong kernel not applicable");
+            if (!pp_ok(d, c.bm, c.bn, ch.splitk)) return fail(FFN_EINVAL, "igemm: ping-pong kernel not applicable");
             const int pplds = 2 * (c.bm + c.bn) * 128 + 12288;
-            const int nt = ((d.M + c.bm - 1) / c.bm) * (d.N / c.bn);
+            const int nt = ((d.M + c.bm - 1) / c.bm) * (d.N / c.bn) * ch.splitk;
             const int grid = nt < device_cus() ? nt : device_cus();
             (void)hipGetLastError();
 #define FFN_PP_LAUNCH(BM_, BN_, RES_, GEGLU_)                                              \
     do {                                                                                   \
         auto kern = igemm_pp_kernel<BM_, BN_, AMODE, RES_, GEGLU_>;                        \
         if ((rc = set_lds(kern, pplds))) return rc;                                        \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pplds, s, d);                      \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pplds, s, d, 1);                   \
     } while (0)
 #define FFN_PP_TILE(BM_)                                                                   \
     do {                                                                                   \
@@ -345,8 +349,25 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
             }                                                                              \
         }                                                                                  \
     } while (0)
+#define FFN_PP_SPLIT(BM_, BN_)                                                             \
+    do {                                                                                   \
+        auto kern = igemm_pp_kernel<BM_, BN_, AMODE, false, false, true>;                  \
+        if ((rc = set_lds(kern, pplds))) return rc;                                        \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pplds, s, d, ch.splitk);           \
+    } while (0)
+            if (ch.splitk > 1) {
+                if (c.bm == 256 && c.bn == 320) FFN_PP_SPLIT(256, 320);
+                else if (c.bm == 256) FFN_PP_SPLIT(256, 256);
+                else if (c.bn == 320) FFN_PP_SPLIT(192, 320);
+                else FFN_PP_SPLIT(192, 256);
+                if ((rc = check_launch("igemm(ping-pong, split-K)"))) return rc;
+                const long nq = (long)d.M * (d.N / 4);
+                LAUNCH(igemm_splitk_reduce_kernel<bf16>, dim3(grid_for(nq)), dim3(256), 0, s, d, ch.splitk);
+                return check_launch("igemm_splitk_reduce");
+            }
             if (c.bm == 256) FFN_PP_TILE(256);
             else FFN_PP_TILE(192);
+#undef FFN_PP_SPLIT
 #undef FFN_PP_TILE
 #undef FFN_PP_LAUNCH
             return check_launch("igemm(ping-pong)");
@@ -446,8 +467,24 @@ static int candidates_for(const ffn_igemm_desc& d, IgChoice* out, int cap) {
             if (hb <= 0 || d.splitk > 1 || 2 * hb + 2 * c.bn * 128 > 160 * 1024) continue;
             if ((cfg == CFG_H_128x320) && (d.flags & FFN_IG_GEGLU)) continue;
         }
-        const bool halo = is_halo_cfg(cfg) || is_pp_cfg(cfg);                      // no split-K variants
-        if (is_pp_cfg(cfg) && (!pp_ok(d, c.bm, c.bn) || d.splitk > 1)) continue;
+        const bool halo = is_halo_cfg(cfg) || is_pp_cfg(cfg);                      // no generic split-K variants
+        if (is_pp_cfg(cfg)) {
+            // ping-pong: unsplit where its epilogue applies; split-K (a divisor of the K-tile count, >= 2 K tiles per slice) where the
+            // output tiles alone leave most of the chip idle
+            const long pt = (long)((d.M + c.bm - 1) / c.bm) * (d.N / (c.bn > 0 ? c.bn : 1));
+            if (d.splitk <= 1 && pp_ok(d, c.bm, c.bn) && n < cap) out[n++] = IgChoice{cfg, 1};
+            if (d.splitk != 1 && pt > 0 && pt < 160 && d.N % c.bn == 0) {
+                const int nkt = d.K / 64;
+                int added = 0;
+                for (int sgo = (int)((384 + pt - 1) / pt); sgo >= 2 && added < 2; --sgo) {
+                    if (d.splitk > 1 && sgo != d.splitk) continue;
+                    if (nkt % sgo != 0 || nkt / sgo < 2 || !pp_ok(d, c.bm, c.bn, sgo)) continue;
+                    if (n < cap) out[n++] = IgChoice{cfg, sgo};
+                    ++added;
+                }
+            }
+            continue;
+        }
         if (c.bm > 64 && c.bm >= 2 * d.M) continue;                                // tile mostly empty
         if (c.bn > 64 && c.bn >= 2 * d.N) continue;
         if (cfg == CFG_64x64 && (long)d.M * d.N > (1l << 22)) continue;

@@ -59,8 +59,12 @@ __device__ __forceinline__ void pp_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int BM, int BN, int AMODE, bool RES, bool GEGLU>
-__global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
+// SPLIT: split-K launch for problems with too few output tiles to fill the chip (the 8x8 / 16x16 levels of the UNet: M = 3072,
+// K up to 23040).  A "tile" of the persistent walk then is (output tile, K slice): slice s of `splitk` multiplies K tiles
+// [s * nk / splitk, (s+1) * nk / splitk) and stores its raw fp32 accumulators to slab s of the workspace (p.ws, [splitk][M][N]);
+// igemm_splitk_reduce_kernel (igemm.h) sums the slabs and applies the epilogue (bias, row bias, residual, SiLU, f32 output).
+template <int BM, int BN, int AMODE, bool RES, bool GEGLU, bool SPLIT = false>
+__global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int splitk = 1) {
     typedef bf16 T;
     constexpr int HM = BM / 2;              // rows per wave (128 or 96)
     constexpr int FM = HM / 16;             // 16-row fragments per wave (8 or 6), FH of them per phase
@@ -83,11 +87,13 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
     const int l15 = lane & 15, g = lane >> 4;
     const int lrow = lane >> 3, csrc = (lane & 7) ^ lrow;
 
+    static_assert(!SPLIT || (!RES && !GEGLU), "split-K slabs carry raw accumulators: the epilogue runs in the reduce kernel");
     const int ntn = p.N / BN;
     const int ntm = (p.M + BM - 1) / BM;
-    const int ntiles = ntm * ntn;
+    const int nsl = SPLIT ? splitk : 1;               // K slices per output tile (the launcher picks a divisor of K / 64)
+    const int ntiles = ntm * ntn * nsl;               // walk index = output tile * nsl + slice
     const int G = gridDim.x;
-    const int nk = p.K / 64;
+    const int nk = p.K / 64 / nsl;                    // K tiles per walk step
     const int first = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, G));
     const int my_tiles = (ntiles - first + G - 1) / G;
     const int S = my_tiles * nk;                      // K tiles this workgroup multiplies, in stream order
@@ -111,6 +117,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
     //   BM = 192: low = pieces 0-5 and 12-17, high = 6-11 and 18-23; phase 3 takes the 12 low ones and 4 high ones, phase 4 the rest.
     // B pieces: rows 8(w + 8i)..
     int l_tile = first, l_kt = 0;
+    int l_k0 = 0;                                     // first K tile of the loader's K slice (split-K launches)
     int a_off[NA];                                    // dense: byte offset of this lane's chunk at K = 0; conv: the same for tap (0,0), ignoring the image border
     int a_yx[NA];                                     // conv: packed (y << 16 | x & 0xffff) of the tap-(0,0) input pixel
     int b_voff;
@@ -137,17 +144,20 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
     const int cpt_rcp = (65536 + cpt - 1) / cpt;
     int ka = 0, tap_ky = 0, tap_kx = 0, tap_off = 0;  // of K tile l_kt; set by k_position()
     auto k_position = [&]() {
+        const int kt = l_k0 + l_kt;
         if (AMODE == AMODE_DENSE) {
-            ka = l_kt * 128;
+            ka = kt * 128;
         } else {
-            const int tap = (l_kt * cpt_rcp) >> 16;
-            ka = (l_kt - tap * cpt) * 128;
+            const int tap = (kt * cpt_rcp) >> 16;
+            ka = (kt - tap * cpt) * 128;
             tap_ky = (tap * 21846) >> 16;
             tap_kx = tap - 3 * tap_ky;
             tap_off = (tap_ky * p.Win + tap_kx) * p.Cin * 2;
         }
     };
-    auto prep = [&](int tile) {                       // loader state at K tile 0 of output tile `tile`
+    auto prep = [&](int wtile) {                      // loader state at the first K tile of walk step `wtile`
+        const int tile = wtile / nsl;
+        l_k0 = (wtile - tile * nsl) * nk;
         const int mt = (tile / ntn) * BM, nt = (tile % ntn) * BN;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -182,12 +192,13 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
     };
     auto issue_b = [&](int i, int buf) {
         if (PP_ABL != 1)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(smem + buf * BUF + ABYTES + (wave + 8 * i) * 1024), 16, b_voff, l_kt * 128 + i * b_step, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(smem + buf * BUF + ABYTES + (wave + 8 * i) * 1024), 16, b_voff, (l_k0 + l_kt) * 128 + i * b_step, 0, 0);
     };
     // column vectors of output tile `tile` for THIS wave: bias[n0 + wc*WN ..) and the row bias of the (at most two: the launcher
     // requires rows_per_batch >= HM) images the wave's HM rows belong to, 2 x 64 floats each (lanes past WN fetch nothing: zeros),
     // into the wave's private 1.5 KiB slot.  6 loads per wave.
     auto issue_colvec = [&](int tile) {
+        if (SPLIT) return;                            // slabs carry raw sums: no column vectors
         const int mt = (tile / ntn) * BM + wr * HM, nt = (tile % ntn) * BN + wc * WN;
         const int bb = mt / p.rows_per_batch;
         char* slot = smem + CV + wave * 1536;
@@ -247,6 +258,13 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
 
     // accumulators of a new output tile start at bias + row bias (+ residual): lane holds C[m = 16 i + l15][n = 16 j + 4 g + r]
     auto init_acc = [&](int tile) {
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            return;
+        }
         const char* slot = smem + CV + wave * 1536;
         const int m0 = (tile / ntn) * BM + wr * HM, n0 = (tile % ntn) * BN + wc * WN;
         const int edge = (m0 / p.rows_per_batch + 1) * p.rows_per_batch - m0 - l15;      // rows i with 16 i >= edge belong to the next image
@@ -281,8 +299,21 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
         }
     };
     // epilogue: convert and store (rows past M fall outside the descriptor and are dropped by the range check)
-    auto store_tile = [&](int tile) {
+    const __amdgpu_buffer_rsrc_t rsrcWs = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, SPLIT ? (int)((long)nsl * p.M * p.N * 4) : 0, 0x00020000);
+    auto store_tile = [&](int wtile) {
+        const int tile = wtile / nsl;
         const int m0 = (tile / ntn) * BM + wr * HM, n0 = (tile % ntn) * BN + wc * WN;
+        if constexpr (SPLIT) {                        // raw fp32 accumulators to slab (wtile % nsl): rows past M are dropped by the range check
+            const int slice = wtile - tile * nsl;
+            const int voff = (l15 * p.N + 4 * g) * 4;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    if (m0 + i * 16 + l15 < p.M)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsrcWs, voff, ((slice * p.M + m0 + i * 16) * p.N + n0 + j * 16) * 4, 0);
+            return;
+        }
         const int voff = (l15 * p.ldo + 4 * g) * 2;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
@@ -378,7 +409,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p) {
             advance();
             // B and A-low of the next K tile have landed (this phase's A-high pieces, and the next output tile's 6 column-vector
             // loads, may still be in flight)
-            if (switched) pp_wait_vmcnt<NA - 2 + 6>();
+            if (switched) pp_wait_vmcnt<NA - 2 + (SPLIT ? 0 : 6)>();
             else pp_wait_vmcnt<NA - 2>();
         }
         __builtin_amdgcn_sched_barrier(0);

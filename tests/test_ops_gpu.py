@@ -436,6 +436,19 @@ def test_every_bf16_igemm_configuration(gpu):
                 ref = torch.nn.functional.conv2d(xr, w.double().cpu(), b.double().cpu(), padding=1) + rb.double().cpu()[:, :, None, None]
                 ref = ref.permute(0, 2, 3, 1).reshape(B, H * W, Cout) + r.double().cpu()
                 assert relerr(out, ref) < tol(dt), (cfg, "conv-pp-shapes", H, W, Cout)
+            # caller-forced split-K (the ping-pong configurations then run their split form: fp32 slabs + the reduce kernel's epilogue)
+            B, H, Cin, Cout = 3, 16, 256, 320
+            x, w = rnd((B, H * H, Cin), dt, gpu, g), rnd((Cout, Cin, 3, 3), dt, gpu, g, (9 * Cin) ** -0.5)
+            b, rb, r = rnd((Cout,), torch.float32, gpu, g), rnd((B, Cout), torch.float32, gpu, g), rnd((B, H * H, Cout), dt, gpu, g)
+            out = ops.conv3x3(x, ops.pack_conv3x3(w, dt), b, B, H, H, Cin, rowbias=rb, residual=r, splitk=12)
+            xr = x.double().cpu().reshape(B, H, H, Cin).permute(0, 3, 1, 2)
+            ref = torch.nn.functional.conv2d(xr, w.double().cpu(), b.double().cpu(), padding=1) + rb.double().cpu()[:, :, None, None]
+            ref = ref.permute(0, 2, 3, 1).reshape(B, H * H, Cout) + r.double().cpu()
+            assert relerr(out, ref) < tol(dt), (cfg, "conv-splitk")
+            M, N, K = 600, 512, 4096
+            x, w, b = rnd((M, K), dt, gpu, g), rnd((N, K), dt, gpu, g, K ** -0.5), rnd((N,), torch.float32, gpu, g)
+            out = ops.linear(x, ops.pack_linear(w, dt), b, K=K, silu=True, splitk=8)
+            assert relerr(out, torch.nn.functional.silu(x.double().cpu() @ w.double().cpu().t() + b.double().cpu())) < tol(dt), (cfg, "dense-splitk")
             # ping-pong kernel: fused nearest-2x upsample, stride 2 (pad 1, and the VAE encoder's pad-right/bottom-only form)
             for (B, H, W, Cin, Cout, stride, pad, up) in [(2, 16, 16, 128, 320, 1, 1, True), (2, 32, 32, 64, 320, 2, 1, False), (3, 32, 32, 64, 256, 2, 0, False)]:
                 x, w = rnd((B, Cin, H, W), dt, gpu, g), rnd((Cout, Cin, 3, 3), dt, gpu, g, (9 * Cin) ** -0.5)

@@ -20,6 +20,12 @@ static void launch(K kern, int grid, int threads, int lds, const ffn_igemm_desc&
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, 0, d);
 }
 
+template <typename K>
+static void launch_pp(K kern, int grid, int threads, int lds, const ffn_igemm_desc& d) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, 0, d, 1);
+}
+
 int main(int argc, char** argv) {
     if (argc < 5) { printf("usage\n"); return 1; }
     const bool conv = !strcmp(argv[1], "conv");
@@ -91,7 +97,7 @@ int main(int argc, char** argv) {
         const int nt = ((d.M + bm - 1) / bm) * (d.N / bn);
         const int grid = nt < 256 ? nt : 256;
         const int lds = 2 * (bm + bn) * 128 + 12288;
-#define PPL(BM_, BN_, AM_, R_, G_) launch(igemm_pp_kernel<BM_, BN_, AM_, R_, G_>, grid, 512, lds, e)
+#define PPL(BM_, BN_, AM_, R_, G_) launch_pp(igemm_pp_kernel<BM_, BN_, AM_, R_, G_>, grid, 512, lds, e)
 #define PPB(BM_)                                                                                                   \
         if (bn == 320) {                                                                                           \
             if (conv) { if (e.residual) PPL(BM_, 320, AMODE_CONV3, true, false); else PPL(BM_, 320, AMODE_CONV3, false, false); } \
