@@ -788,7 +788,7 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
 
 // ---- norms -------------------------------------------------------------------------------------------------------
 extern "C" int ffn_gn_nchunk(int HW) {
-    int n = HW / 64;
+    int n = HW / 128;
     if (n < 1) n = 1;
     if (n > 256) n = 256;
     return n;
@@ -836,7 +836,9 @@ extern "C" int ffn_gn_stats(void* stream, int dtype, const void* x, const float*
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nchunk = ffn_gn_nchunk(HW);
     const int ppc = (HW + nchunk - 1) / nchunk;
-    const int lds = 2 * C * (int)sizeof(float);
+    const int epc_ = dtype == FFN_F32 ? 4 : 8;
+    const int cols_ = C / epc_ < 256 ? C / epc_ : 256;
+    const int lds = (256 / cols_ > 0 ? 256 / cols_ : 1) * cols_ * 2 * epc_ * (int)sizeof(float);      // [pixel rows of threads][columns][2 x EPC]
     if (dtype == FFN_F32)
         LAUNCH(gn_partial_kernel<float>, dim3(nchunk, B), dim3(256), lds, s, (const float*)x, partial_ws, HW, C, ppc);
     else

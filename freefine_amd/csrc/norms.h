@@ -15,59 +15,66 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
                                                          int C, int pix_per_chunk) {
     constexpr int EPC = DT<T>::EPC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* ls = reinterpret_cast<float*>(smem);  // [C][2]
+    float* ls = reinterpret_cast<float*>(smem);  // [ppi][C][2] per-thread-row partials (round 2: no LDS atomics -- 16 contended atomic
+                                                 // adds per thread made this HBM-bound kernel run at 2.7 TB/s)
     const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int cch = C / EPC;                 // 16-byte chunks per pixel
-    const int cols = min(cch, 256);          // chunk columns handled concurrently
-    const int ppi = max(1, 256 / cch);       // pixels in flight per iteration
     const int tid = threadIdx.x;
-    for (int i = tid; i < 2 * C; i += 256) ls[i] = 0.f;
-    __syncthreads();
     const int p0 = chunk * pix_per_chunk;
     const int p1 = min(HW, p0 + pix_per_chunk);
+    float* dst = partial + ((long)b * nchunk + chunk) * 2 * C;
     for (int cbase = 0; cbase < cch; cbase += 256) {
+        const int cols = min(cch - cbase, 256);  // chunk columns handled concurrently in this sweep
+        const int ppi = max(1, 256 / cols);       // pixel rows of threads
         const int cc = cbase + tid % cols, pp = tid / cols;
-        if (cc >= cch || pp >= ppi) continue;
+        const bool active = pp < ppi;
         float s[EPC], ss[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) s[e] = ss[e] = 0.f;
-        // four pixels in flight per thread: a single dependent load per iteration made this kernel latency bound
-        const T* src = x + ((long)b * HW) * C + cc * EPC;
-        int px = p0 + pp;
-        for (; px + 3 * ppi < p1; px += 4 * ppi) {
-            u32x4 v[4];
+        if (active) {
+            // eight pixels in flight per thread: a single dependent load per iteration made this kernel latency bound
+            const T* src = x + ((long)b * HW) * C + cc * EPC;
+            int px = p0 + pp;
+            for (; px + 7 * ppi < p1; px += 8 * ppi) {
+                u32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u32x4*>(src + (long)(px + u * ppi) * C);
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const u32x4*>(src + (long)(px + u * ppi) * C);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
+                    float f[EPC];
+                    DT<T>::unpack(v[u], f);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        s[e] += f[e];
+                        ss[e] += f[e] * f[e];
+                    }
+                }
+            }
+            for (; px < p1; px += ppi) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(src + (long)px * C);
                 float f[EPC];
-                DT<T>::unpack(v[u], f);
+                DT<T>::unpack(v, f);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     s[e] += f[e];
                     ss[e] += f[e] * f[e];
                 }
             }
-        }
-        for (; px < p1; px += ppi) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(src + (long)px * C);
-            float f[EPC];
-            DT<T>::unpack(v, f);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                s[e] += f[e];
-                ss[e] += f[e] * f[e];
+                ls[(pp * cols + (cc - cbase)) * 2 * EPC + 2 * e] = s[e];
+                ls[(pp * cols + (cc - cbase)) * 2 * EPC + 2 * e + 1] = ss[e];
             }
         }
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            atomicAdd(&ls[2 * (cc * EPC + e)], s[e]);
-            atomicAdd(&ls[2 * (cc * EPC + e) + 1], ss[e]);
+        __syncthreads();
+        // fixed-order sum over the pixel rows of threads (deterministic)
+        for (int i = tid; i < cols * 2 * EPC; i += 256) {
+            float acc = 0.f;
+            for (int r = 0; r < ppi; ++r) acc += ls[r * cols * 2 * EPC + i];
+            dst[cbase * 2 * EPC + i] = acc;      // [c][2] with c = (cbase + column) * EPC + e: same interleaving as ls
         }
+        __syncthreads();
     }
-    __syncthreads();
-    float* dst = partial + ((long)b * nchunk + chunk) * 2 * C;
-    for (int i = tid; i < 2 * C; i += 256) dst[i] = ls[i];
 }
 
 // ---- (2) finalize: grid (G, B), 64 threads: scale[b][c] = rstd*gamma[c], shift[b][c] = beta[c]-mean*rstd*gamma[c]
