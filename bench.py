@@ -227,6 +227,17 @@ def main():
     models = [model] + [add_sibling(model) for _ in range(args.concurrent - 1)]
     streams = [torch.cuda.Stream(device=device) for _ in models]
     outs = [None] * len(models)
+    if world > 1:
+        # every rank launches the SAME igemm configurations: one eager edit tunes every shape of the schedule, rank 0's table is
+        # broadcast, and only then are the forward graphs captured (the tuner picks by timing, which may differ between GPUs;
+        # identical tables make the bf16 results of the sharded run independent of which rank edited a case)
+        from freefine_amd import dist as _fdist
+        was = model.unet.use_graph
+        model.unet.use_graph = False
+        edit_once(model, args, rank * 1000 + 999)
+        model.unet.use_graph = was
+        torch.cuda.synchronize()
+        _fdist.sync_tune_table(0)
     for j, (m, st) in enumerate(zip(models, streams)):
         with torch.cuda.stream(st):
             for i in range(max(args.warmup, 1 if args.concurrent > 1 else 0)):
