@@ -257,7 +257,7 @@ static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn, int splitk = 1) {
     const long lim = (1l << 31) - 4096;
     if (d.K % 64 != 0 || d.K < 128 || d.N % bn != 0 || d.M < bm) return false;
     if (splitk > 1) {       // split-K: raw fp32 slabs + igemm_splitk_reduce_kernel (which applies every plain epilogue option)
-        if (!can_split(d) || (d.K / 64) % splitk != 0 || (long)splitk * d.M * d.N * 4 > d.ws_bytes || (long)splitk * d.M * d.N * 4 >= lim) return false;
+        if (!can_split(d) || (d.K / 64) % splitk != 0 || d.K / 64 / splitk < 2 || (long)splitk * d.M * d.N * 4 > d.ws_bytes || (long)splitk * d.M * d.N * 4 >= lim) return false;
     } else {
         if (d.alpha != 1.0f || (d.flags & ~FFN_IG_GEGLU)) return false;
         if ((d.flags & FFN_IG_GEGLU) && bn != 256) return false;

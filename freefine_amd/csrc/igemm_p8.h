@@ -257,57 +257,59 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     typedef std::integral_constant<int, FH> I4_t;
 
     // accumulators of a new output tile start at bias + row bias (+ residual): lane holds C[m = 16 i + l15][n = 16 j + 4 g + r]
-    auto init_acc = [&](int tile) {
+    // The epilogue of a tile is split into its low and high row halves: the low rows are final after phase 3 of the tile's last K
+    // tile and are stored (and re-started for the next tile) in that K tile's phase-4 load section; the high rows are stored and
+    // re-started in the phase-2 load section of the next tile's first K tile -- each half beside an MFMA phase of the other wave
+    // group, instead of both groups running their whole epilogue back to back with the matrix pipe idle.
+    auto init_rows = [&](int tile, auto I0) {
+        constexpr int i0 = decltype(I0)::value;
         if constexpr (SPLIT) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+            for (int i = i0; i < i0 + FH; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             return;
         }
         const char* slot = smem + CV + wave * 1536;
         const int m0 = (tile / ntn) * BM + wr * HM, n0 = (tile % ntn) * BN + wc * WN;
-        const int edge = (m0 / p.rows_per_batch + 1) * p.rows_per_batch - m0 - l15;      // rows i with 16 i >= edge belong to the next image
-        f32x4 cv[FN], cv2[FN];
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(slot + (j * 16 + 4 * g) * 4);
-            cv[j] = bv + *reinterpret_cast<const f32x4*>(slot + 512 + (j * 16 + 4 * g) * 4);
-            cv2[j] = bv + *reinterpret_cast<const f32x4*>(slot + 1024 + (j * 16 + 4 * g) * 4);
-        }
+        const int E = (m0 / p.rows_per_batch + 1) * p.rows_per_batch - m0;      // wave rows >= E belong to the next image (E >= HM: none)
         const int voff = (l15 * p.ldr + 4 * g) * 2;
+        // the row bias slot (first / next image) is a per-lane LDS address; bias + row bias are re-read per fragment row rather than
+        // held in registers across the rows (the accumulators, the fragments just read and the loader state leave ~25 free registers)
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const bool nxt = i * 16 >= edge;
+        for (int i = i0; i < i0 + FH; ++i) {
+            const int rb_off = (i * 16 + l15 >= E) ? 1024 : 512;
+            u32x2 w[FN];
             if constexpr (RES) {
-                u32x2 w[FN];
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     w[j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrcR, voff, ((m0 + i * 16) * p.ldr + n0 + j * 16) * 2, 0));
+            }
 #pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const f32x4 c = nxt ? cv2[j] : cv[j];
+            for (int j = 0; j < FN; ++j) {
+                const f32x4 c = *reinterpret_cast<const f32x4*>(slot + (j * 16 + 4 * g) * 4) + *reinterpret_cast<const f32x4*>(slot + rb_off + (j * 16 + 4 * g) * 4);
+                if constexpr (RES) {
                     acc[i][j][0] = c[0] + __uint_as_float(w[j][0] << 16);
                     acc[i][j][1] = c[1] + __uint_as_float(w[j][0] & 0xffff0000u);
                     acc[i][j][2] = c[2] + __uint_as_float(w[j][1] << 16);
                     acc[i][j][3] = c[3] + __uint_as_float(w[j][1] & 0xffff0000u);
+                } else {
+                    acc[i][j] = c;
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = nxt ? cv2[j] : cv[j];
             }
         }
     };
     // epilogue: convert and store (rows past M fall outside the descriptor and are dropped by the range check)
     const __amdgpu_buffer_rsrc_t rsrcWs = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, SPLIT ? (int)((long)nsl * p.M * p.N * 4) : 0, 0x00020000);
-    auto store_tile = [&](int wtile) {
+    auto store_rows = [&](int wtile, auto I0) {
+        constexpr int i0 = decltype(I0)::value;
         const int tile = wtile / nsl;
         const int m0 = (tile / ntn) * BM + wr * HM, n0 = (tile % ntn) * BN + wc * WN;
         if constexpr (SPLIT) {                        // raw fp32 accumulators to slab (wtile % nsl): rows past M are dropped by the range check
             const int slice = wtile - tile * nsl;
             const int voff = (l15 * p.N + 4 * g) * 4;
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+            for (int i = i0; i < i0 + FH; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     if (m0 + i * 16 + l15 < p.M)
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         }
         const int voff = (l15 * p.ldo + 4 * g) * 2;
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
+        for (int i = i0; i < i0 + FH; ++i) {
             if constexpr (GEGLU) {
 #pragma unroll
                 for (int j = 0; j + 1 < FN; j += 2) {
@@ -353,7 +355,9 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     if (wr == 1) pp_barrier();                        // the lagging group starts one barrier late
 
     int c_tile = first, c_kt = 0, buf = 0;
-    init_acc(c_tile);
+    int p_tile = -1;                                  // tile whose high rows still sit in the accumulators (-1: none)
+    init_rows(c_tile, I0_t{});
+    init_rows(c_tile, I4_t{});
     for (int s = 0; s < S; ++s) {
         const bool more = s + 1 < S;                  // another K tile follows in this workgroup's stream: request it during this one
         const int nb = buf ^ 1;
@@ -380,6 +384,11 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         if (more) {
 #pragma unroll
             for (int i = NB1; i < FN; ++i) issue_b(i, nb);
+        }
+        if (p_tile >= 0) {                            // first K tile of a new output tile: the previous tile's high rows leave now
+            store_rows(p_tile, I4_t{});
+            init_rows(c_tile, I4_t{});
+            p_tile = -1;
         }
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
@@ -412,6 +421,10 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
             if (switched) pp_wait_vmcnt<NA - 2 + (SPLIT ? 0 : 6)>();
             else pp_wait_vmcnt<NA - 2>();
         }
+        if (c_kt == nk - 1) {                         // last K tile of the output tile: its low rows are final since phase 3
+            store_rows(c_tile, I0_t{});
+            if (more) init_rows(c_tile + G, I0_t{});
+        }
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
         mfma_rows(I4_t{});
@@ -419,12 +432,12 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         pp_barrier();
 
         buf = nb;
-        if (++c_kt == nk) {                           // output tile complete
-            store_tile(c_tile);
+        if (++c_kt == nk) {                           // output tile complete (high rows are stored in the next K tile's phase 2, or below)
+            p_tile = c_tile;
             c_kt = 0;
             c_tile += G;
-            if (more) init_acc(c_tile);
         }
     }
+    if (p_tile >= 0) store_rows(p_tile, I4_t{});
     if (wr == 0) pp_barrier();                        // balance the lagging group's extra barrier
 }
