@@ -613,6 +613,7 @@ static bool tuned_lookup(const ffn_igemm_desc& d, IgChoice* ch) {
     return true;
 }
 
+static bool pp_trans_tile(const ffn_igemm_desc& d, int* bm, int* bn);
 extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d, char* buf, int len) {
     REQUIRE(d && buf && len > 0, "igemm_kernel_name: null argument");
     int bm, bn, sk, ns, nw;
@@ -625,13 +626,18 @@ extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d, char* b
             return FFN_OK;
         }
         if (is_pp_cfg(ch.cfg)) {
-            snprintf(buf, len, "void igemm_pp_kernel<%d, %d, %d, %s, %s>(ffn_igemm_desc)", c.bm, c.bn, d->conv ? 1 : 0, d->residual ? "true" : "false",
-                     (d->flags & FFN_IG_GEGLU) ? "true" : "false");
+            const bool split = ch.splitk > 1;
+            snprintf(buf, len, "void igemm_pp_kernel<%d, %d, %d, %s, %s, %s, false>(ffn_igemm_desc, int)", c.bm, c.bn, d->conv ? 1 : 0,
+                     (!split && d->residual) ? "true" : "false", (!split && (d->flags & FFN_IG_GEGLU)) ? "true" : "false", split ? "true" : "false");
             return FFN_OK;
         }
         const bool fastk = (d->conv ? d->Cin % 64 == 0 : d->K % 64 == 0) && (long)d->K * 2 + 256 <= (long)sizeof(g_zero_page);
         snprintf(buf, len, "void igemm_glds_kernel<bf16, %d, %d, %d, true, 2, %d, %d, %s>(ffn_igemm_desc)", c.bm, c.bn, d->conv ? 1 : 0, c.nwm, c.nwn,
                  fastk ? "true" : "false");
+        return FFN_OK;
+    }
+    if (dtype == FFN_BF16 && (d->flags & FFN_IG_OUT_TRANSPOSED) && !d->conv && pp_trans_tile(*d, &bm, &bn)) {
+        snprintf(buf, len, "void igemm_pp_kernel<%d, %d, 0, false, false, false, true>(ffn_igemm_desc, int)", bm, bn);
         return FFN_OK;
     }
     igemm_plan_for(dtype, *d, &bm, &bn, &sk);
@@ -645,6 +651,44 @@ extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d, char* b
     }
     return FFN_OK;
 }
+// transposed-output (V^T) launches on the ping-pong kernel: deterministic tile choice (no tuning): the tile height whose tile count
+// wastes the least of the last round of 256 workgroups
+static bool pp_trans_tile(const ffn_igemm_desc& d, int* bm, int* bn) {
+    static const bool on = [] { const char* e = getenv("FFN_IGEMM_PP_TRANS"); return !(e && atoi(e) == 0); }();
+    if (!on) return false;
+    const long lim = (1l << 31) - 4096;
+    *bn = d.N % 320 == 0 ? 320 : (d.N % 256 == 0 ? 256 : 0);
+    if (!*bn || d.K % 64 != 0 || d.K < 128 || d.alpha != 1.0f || d.rows_per_batch % 16 != 0 || d.M % 4 != 0) return false;
+    if ((long)(d.M + 256) * d.lda * 2 >= lim || (long)d.N * d.Kpad * 2 >= lim) return false;
+    if ((long)((d.M + d.rows_per_batch - 1) / d.rows_per_batch) * d.N * d.ldo * 2 >= lim) return false;
+    long best = -1;
+    for (int h : {256, 192}) {
+        if (d.M < h) continue;
+        const long tiles = (long)((d.M + h - 1) / h) * (d.N / *bn);
+        const long cost = ((tiles + device_cus() - 1) / device_cus()) * h;
+        if (best < 0 || cost < best) { best = cost; *bm = h; }
+    }
+    return best >= 0;
+}
+static int launch_pp_trans(hipStream_t s, const ffn_igemm_desc& d, int bm, int bn) {
+    const int pplds = 2 * (bm + bn) * 128 + 12288;
+    const int nt = ((d.M + bm - 1) / bm) * (d.N / bn);
+    const int grid = nt < device_cus() ? nt : device_cus();
+    int rc = FFN_OK;
+    (void)hipGetLastError();
+#define FFN_PP_TR(BM_, BN_)                                                                         \
+    do {                                                                                            \
+        auto kern = igemm_pp_kernel<BM_, BN_, AMODE_DENSE, false, false, false, true>;              \
+        if ((rc = set_lds(kern, pplds))) return rc;                                                 \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pplds, s, d, 1);                            \
+    } while (0)
+    if (bm == 256 && bn == 320) FFN_PP_TR(256, 320);
+    else if (bm == 256) FFN_PP_TR(256, 256);
+    else if (bn == 320) FFN_PP_TR(192, 320);
+    else FFN_PP_TR(192, 256);
+#undef FFN_PP_TR
+    return check_launch("igemm(ping-pong, transposed)");
+}
 template <typename T>
 static int dispatch_igemm(hipStream_t s, const ffn_igemm_desc& d) {
     const bool tr = d.flags & FFN_IG_OUT_TRANSPOSED;
@@ -653,7 +697,13 @@ static int dispatch_igemm(hipStream_t s, const ffn_igemm_desc& d) {
         if constexpr (sizeof(T) == 2) return tuned_bf16<AMODE_CONV3>(s, d);
         return dispatch_igemm_tile<T, AMODE_CONV3, true>(s, d);
     }
-    if (tr) return dispatch_igemm_tile<T, AMODE_DENSE, false>(s, d);
+    if (tr) {
+        if constexpr (sizeof(T) == 2) {
+            int bm, bn;
+            if (pp_trans_tile(d, &bm, &bn)) return launch_pp_trans(s, d, bm, bn);
+        }
+        return dispatch_igemm_tile<T, AMODE_DENSE, false>(s, d);
+    }
     if constexpr (sizeof(T) == 2) return tuned_bf16<AMODE_DENSE>(s, d);
     return dispatch_igemm_tile<T, AMODE_DENSE, true>(s, d);
 }

@@ -63,7 +63,9 @@ __device__ __forceinline__ void pp_barrier() {
 // K up to 23040).  A "tile" of the persistent walk then is (output tile, K slice): slice s of `splitk` multiplies K tiles
 // [s * nk / splitk, (s+1) * nk / splitk) and stores its raw fp32 accumulators to slab s of the workspace (p.ws, [splitk][M][N]);
 // igemm_splitk_reduce_kernel (igemm.h) sums the slabs and applies the epilogue (bias, row bias, residual, SiLU, f32 output).
-template <int BM, int BN, int AMODE, bool RES, bool GEGLU, bool SPLIT = false>
+// TRANS: transposed output out[b][n][s] (m = b * rows_per_batch + s; the V^T operand of ffn_attn), bias only: the MFMA operands swap
+// roles so that a lane holds four consecutive rows m of one column n -> 8-byte stores along s.
+template <int BM, int BN, int AMODE, bool RES, bool GEGLU, bool SPLIT = false, bool TRANS = false>
 __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int splitk = 1) {
     typedef bf16 T;
     constexpr int HM = BM / 2;              // rows per wave (128 or 96)
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     const int lrow = lane >> 3, csrc = (lane & 7) ^ lrow;
 
     static_assert(!SPLIT || (!RES && !GEGLU), "split-K slabs carry raw accumulators: the epilogue runs in the reduce kernel");
+    static_assert(!TRANS || (!RES && !GEGLU && !SPLIT && AMODE == AMODE_DENSE), "transposed output: dense A, bias only");
     const int ntn = p.N / BN;
     const int ntm = (p.M + BM - 1) / BM;
     const int nsl = SPLIT ? splitk : 1;               // K slices per output tile (the launcher picks a divisor of K / 64)
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     const int nbatch = (p.M + p.rows_per_batch - 1) / p.rows_per_batch;
     const __amdgpu_buffer_rsrc_t rsrcRb =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.rowbias), 0, p.rowbias ? ((nbatch - 1) * p.ldrb + p.N) * 4 : 0, 0x00020000);
-    const long o_bytes = (long)p.M * p.ldo * 2;
+    const long o_bytes = TRANS ? (long)((p.M + p.rows_per_batch - 1) / p.rows_per_batch) * p.N * p.ldo * 2 : (long)p.M * p.ldo * 2;
     const __amdgpu_buffer_rsrc_t rsrcO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)o_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, RES ? (int)((long)p.M * p.ldr * 2) : 0, 0x00020000);
 
@@ -250,7 +253,10 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
 #pragma unroll
         for (int i = 0; i < FH; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) DT<T>::mma(fb[j], fa[i], acc[i0 + i][j]);
+            for (int j = 0; j < FN; ++j) {
+                if constexpr (TRANS) DT<T>::mma(fa[i], fb[j], acc[i0 + i][j]);      // C[m = 4g + r][n = l15]
+                else DT<T>::mma(fb[j], fa[i], acc[i0 + i][j]);                      // C[m = l15][n = 4g + r]
+            }
         __builtin_amdgcn_s_setprio(0);
     };
     typedef std::integral_constant<int, 0> I0_t;
@@ -271,6 +277,15 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
             return;
         }
         const char* slot = smem + CV + wave * 1536;
+        if constexpr (TRANS) {                        // bias of column n = 16 j + l15, the same for the lane's four rows
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const float bv = *reinterpret_cast<const float*>(slot + (j * 16 + l15) * 4);
+#pragma unroll
+                for (int i = i0; i < i0 + FH; ++i) acc[i][j] = f32x4{bv, bv, bv, bv};
+            }
+            return;
+        }
         const int m0 = (tile / ntn) * BM + wr * HM, n0 = (tile % ntn) * BN + wc * WN;
         const int E = (m0 / p.rows_per_batch + 1) * p.rows_per_batch - m0;      // wave rows >= E belong to the next image (E >= HM: none)
         const int voff = (l15 * p.ldr + 4 * g) * 2;
@@ -314,6 +329,22 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
                 for (int j = 0; j < FN; ++j)
                     if (m0 + i * 16 + l15 < p.M)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsrcWs, voff, ((slice * p.M + m0 + i * 16) * p.N + n0 + j * 16) * 4, 0);
+            return;
+        }
+        if constexpr (TRANS) {                        // out[(b * N + n) * ldo + s], four consecutive s per lane (rows_per_batch % 16 == 0)
+            const int voff = (l15 * p.ldo + 4 * g) * 2;
+#pragma unroll
+            for (int i = i0; i < i0 + FH; ++i) {
+                const int mb = m0 + i * 16;
+                const int bb = mb / p.rows_per_batch, sb = mb - bb * p.rows_per_batch;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    u32x2 w;
+                    w[0] = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+                    w[1] = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+                    if (mb + 4 * g < p.M) __builtin_amdgcn_raw_buffer_store_b64(w, rsrcO, voff, ((bb * p.N + n0 + j * 16) * p.ldo + sb) * 2, 0);
+                }
+            }
             return;
         }
         const int voff = (l15 * p.ldo + 4 * g) * 2;

@@ -66,7 +66,10 @@ typedef struct ffn_igemm_desc {
     long ws_bytes;
 } ffn_igemm_desc;
 int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
-/* bf16 problems: the first time a problem shape is seen outside stream capture, ffn_igemm times its few plausible (tile, K-split)
+/* Kernel families behind ffn_igemm (freefine_amd/csrc): igemm_pp_kernel (igemm_p8.h; bf16 -- 256- or 192-row "ping-pong" tiles with
+ * LDS-DMA operands in flight across barriers, the default wherever N is a multiple of 256 or 320 and K a multiple of 64),
+ * igemm_glds_kernel / igemm_halo_kernel (igemm.h; every other bf16 shape and all of f32).
+ * bf16 problems: the first time a problem shape is seen outside stream capture, ffn_igemm times its few plausible (tile, K-split)
  * configurations on the caller's stream (this one call synchronises the stream and launches the kernel several times: `out` must
  * not alias `residual`) and caches the winner; FFN_IGEMM_TUNE=0 in the environment keeps the deterministic rule-based choice
  * (f32 always uses it).  Testing hooks: the number of bf16 configurations, and forcing one (-1 = off; returns the previous value). */
@@ -117,6 +120,9 @@ typedef struct ffn_attn_desc {
     ffn_attn_entry e[FFN_ATT_MAXP * FFN_ATT_MAXB]; /* entry (p,b) at p*FFN_ATT_MAXB + b */
 } ffn_attn_desc;
 int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d);
+/* bf16 launches with D = 64, Sk % 64 == 0, S >= 128 and no degenerate (uniform-softmax) entry run attn_pp_kernel (attention_pp.h:
+ * software-pipelined, 8 waves in two alternating groups); everything else attn_kernel (attention.h).  Same results up to fp32
+ * summation order.  FFN_ATTN_PP=0 in the environment forces attn_kernel. */
 /* padded head dim / query fragments per wave of the instantiation ffn_attn dispatches for head dim D */
 int ffn_attn_variant(int dtype, int D, int* dp, int* qf);
 /* the kernel instantiation ffn_attn launches for this problem, spelled like rocprofv3's kernel trace */
