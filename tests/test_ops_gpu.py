@@ -73,16 +73,18 @@ def test_linear_rowbias_and_geglu(gpu, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("S", [256, 77])
+@pytest.mark.parametrize("S", [256, 77, 400])
 def test_linear_transposed(gpu, dtype, S):
+    """S = 256 / 400 (bf16): the ping-pong kernel's transposed-output form (400: ragged last tile, 5 images, bias); 77: 2-stage kernel"""
     from freefine_amd import ops
     g = torch.Generator().manual_seed(5)
-    B, K, N = 3, 320, 320
+    B, K, N = (5, 320, 640) if S == 400 else (3, 320, 320)
     x = rnd((B, S, K), dtype, gpu, g)
     w = rnd((N, K), dtype, gpu, g, K ** -0.5)
+    b = rnd((N,), torch.float32, gpu, g) if S == 400 else None
     ld = (S + 7) // 8 * 8
-    out = ops.linear(x, ops.pack_linear(w, dtype), None, rows_per_batch=S, transposed_ld=ld)
-    ref = (x.double() @ w.double().t()).transpose(1, 2)
+    out = ops.linear(x, ops.pack_linear(w, dtype), b, rows_per_batch=S, transposed_ld=ld)
+    ref = (x.double() @ w.double().t() + (b.double() if b is not None else 0.0)).transpose(1, 2)
     assert out.shape == (B, N, ld)
     assert relerr(out[:, :, :S], ref) < tol(dtype)
     assert (out[:, :, S:] == 0).all()
