@@ -47,7 +47,7 @@
 #include "igemm.h"
 
 #ifndef PP_ABL
-#define PP_ABL 0      // timing-only ablation builds of tools/native/pp_bench.hip: 1 = no global loads, 2 = no counted waits (results garbage)
+#define PP_ABL 0      // timing-only ablation builds of tools/native/pp_bench.hip: 1 = no global loads, 2 = no counted waits, 3 = GEGLU without the GELU, 4 = no epilogue stores (results garbage)
 #endif
 template <int N>
 __device__ __forceinline__ void pp_wait_vmcnt() {
@@ -65,6 +65,9 @@ __device__ __forceinline__ void pp_barrier() {
 // igemm_splitk_reduce_kernel (igemm.h) sums the slabs and applies the epilogue (bias, row bias, residual, SiLU, f32 output).
 // TRANS: transposed output out[b][n][s] (m = b * rows_per_batch + s; the V^T operand of ffn_attn), bias only: the MFMA operands swap
 // roles so that a lane holds four consecutive rows m of one column n -> 8-byte stores along s.
+#ifdef PP_TRACE
+__device__ unsigned long long pp_trace[256 * 64];   // tools/native/pp_bench.hip: 100 MHz timestamps around the low-row stores of each tile
+#endif
 template <int BM, int BN, int AMODE, bool RES, bool GEGLU, bool SPLIT = false, bool TRANS = false>
 __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int splitk = 1) {
     typedef bf16 T;
@@ -77,6 +80,9 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     constexpr int ABYTES = BM * 128, BBYTES = BN * 128, BUF = ABYTES + BBYTES;
     constexpr int CV = 2 * BUF;             // column vectors: per wave [bias | row bias of the first image | of the next image] x 128 floats
     constexpr int NB1 = (FN + 1) / 2;       // B pieces requested in phase 1 (the rest in phase 2)
+    // store instructions of one half-tile epilogue (every one is issued: no lane predicate around them); bf16 row-major output goes
+    // out as pairs of fragments (store_rows)
+    constexpr int NST = (SPLIT || TRANS) ? FH * FN : (GEGLU ? FH * FN / 2 : FH * ((FN + 1) / 2));
     constexpr int OOB = (int)0x80000000;
     static_assert((BM == 256 || BM == 192) && (BN == 256 || BN == 320), "tiles built for this kernel");
     static_assert(!GEGLU || FN % 2 == 0, "GEGLU pairs hidden / gate column blocks inside a wave");
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         for (int i = 0; i < NA; ++i) {
             const int m = mt + 8 * apiece[i] + lrow;
             if (AMODE == AMODE_DENSE) {
-                a_off[i] = m < p.M ? m * (p.lda * 2) + csrc * 16 : OOB;
+                a_off[i] = m < p.M ? (PP_ABL == 10 ? m & 255 : m) * (p.lda * 2) + csrc * 16 : OOB;      // 10: every tile reads the same 256 rows (L2-hot A; results garbage)
             } else {
                 const int hw = p.Hout * p.Wout;
                 const int b = m / hw, rem = m - b * hw;
@@ -288,28 +294,38 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         }
         const int m0 = (tile / ntn) * BM + wr * HM, n0 = (tile % ntn) * BN + wc * WN;
         const int E = (m0 / p.rows_per_batch + 1) * p.rows_per_batch - m0;      // wave rows >= E belong to the next image (E >= HM: none)
-        const int voff = (l15 * p.ldr + 4 * g) * 2;
         // the row bias slot (first / next image) is a per-lane LDS address; bias + row bias are re-read per fragment row rather than
         // held in registers across the rows (the accumulators, the fragments just read and the loader state leave ~25 free registers)
+        // residual: all loads of the half tile first (their registers are the half's own, dead, accumulators' worth), ONE wait, then
+        // the sums -- hipcc waits vmcnt(0) at the first use of a register-destination load while LDS-DMA loads are in flight, so a
+        // load-use pair per fragment row would drain the K-tile stream once per row
+        constexpr int RB = (BM == 256 && BN == 320) ? 2 : FH;      // fragment rows per batch (register budget of the largest tile)
 #pragma unroll
-        for (int i = i0; i < i0 + FH; ++i) {
-            const int rb_off = (i * 16 + l15 >= E) ? 1024 : 512;
-            u32x2 w[FN];
+        for (int ib = i0; ib < i0 + FH; ib += RB) {
+            u32x2 w[RES ? RB : 1][RES ? FN : 1];
             if constexpr (RES) {
+                const int voff = (l15 * p.ldr + 4 * g) * 2;
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    w[j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrcR, voff, ((m0 + i * 16) * p.ldr + n0 + j * 16) * 2, 0));
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        w[i][j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrcR, voff, ((m0 + (ib + i) * 16) * p.ldr + n0 + j * 16) * 2, 0));
             }
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const f32x4 c = *reinterpret_cast<const f32x4*>(slot + (j * 16 + 4 * g) * 4) + *reinterpret_cast<const f32x4*>(slot + rb_off + (j * 16 + 4 * g) * 4);
-                if constexpr (RES) {
-                    acc[i][j][0] = c[0] + __uint_as_float(w[j][0] << 16);
-                    acc[i][j][1] = c[1] + __uint_as_float(w[j][0] & 0xffff0000u);
-                    acc[i][j][2] = c[2] + __uint_as_float(w[j][1] << 16);
-                    acc[i][j][3] = c[3] + __uint_as_float(w[j][1] & 0xffff0000u);
-                } else {
-                    acc[i][j] = c;
+            for (int i = ib; i < ib + RB && i < i0 + FH; ++i) {
+                const int rb_off = (i * 16 + l15 >= E) ? 1024 : 512;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(slot + (j * 16 + 4 * g) * 4) + *reinterpret_cast<const f32x4*>(slot + rb_off + (j * 16 + 4 * g) * 4);
+                    if constexpr (RES) {
+                        const unsigned w0 = w[i - ib][j][0], w1 = w[i - ib][j][1];
+                        acc[i][j][0] = c[0] + __uint_as_float(w0 << 16);
+                        acc[i][j][1] = c[1] + __uint_as_float(w0 & 0xffff0000u);
+                        acc[i][j][2] = c[2] + __uint_as_float(w1 << 16);
+                        acc[i][j][3] = c[3] + __uint_as_float(w1 & 0xffff0000u);
+                    } else {
+                        acc[i][j] = c;
+                    }
                 }
             }
         }
@@ -320,19 +336,34 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         constexpr int i0 = decltype(I0)::value;
         const int tile = wtile / nsl;
         const int m0 = (tile / ntn) * BM + wr * HM, n0 = (tile % ntn) * BN + wc * WN;
+        // Lane order of the stores.  In the MFMA result a lane holds 4 consecutive columns of row l15, so the 64 lanes of a store
+        // instruction touch 16 rows and NO two neighbouring lanes are neighbours in memory: the address unit takes such an
+        // instruction one lane at a time (measured, tools/native/store_bw.hip: 7 B/clk/CU, and it serves the CU's loads in the same
+        // queue, so the K-tile stream stands still meanwhile: 20k cycles per 256 x 320 tile).  Every packed register is therefore
+        // permuted across the wave first (ds_bpermute: LDS crossbar, no LDS memory) so that lane 4 r + c holds columns 4c..4c+3 of
+        // row r: runs of four lanes write 32 contiguous bytes, 24 B/clk/CU.
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                  // lane constants of the epilogue are recomputed here, not carried through the K loop (registers)
+        const int pr = ln >> 2, pg = ln & 3;          // row and column group this lane stores
+        const int paddr = (pr + 16 * pg) * 4;         // ds_bpermute address: the lane that computed them
+        auto perm = [&](unsigned v) { return (unsigned)__builtin_amdgcn_ds_bpermute(paddr, (int)v); };
         if constexpr (SPLIT) {                        // raw fp32 accumulators to slab (wtile % nsl): rows past M are dropped by the range check
             const int slice = wtile - tile * nsl;
-            const int voff = (l15 * p.N + 4 * g) * 4;
+            const int voff = (pr * p.N + 4 * pg) * 4;
 #pragma unroll
-            for (int i = i0; i < i0 + FH; ++i)
+            for (int i = i0; i < i0 + FH; ++i) {
+                const int vo = m0 + i * 16 + pr < p.M ? voff : OOB;           // a row past M would land in the next slab: out of range instead
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    if (m0 + i * 16 + l15 < p.M)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsrcWs, voff, ((slice * p.M + m0 + i * 16) * p.N + n0 + j * 16) * 4, 0);
+                for (int j = 0; j < FN; ++j) {
+                    u32x4 w = __builtin_bit_cast(u32x4, acc[i][j]);
+                    w[0] = perm(w[0]); w[1] = perm(w[1]); w[2] = perm(w[2]); w[3] = perm(w[3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rsrcWs, vo, ((slice * p.M + m0 + i * 16) * p.N + n0 + j * 16) * 4, 0);
+                }
+            }
             return;
         }
         if constexpr (TRANS) {                        // out[(b * N + n) * ldo + s], four consecutive s per lane (rows_per_batch % 16 == 0)
-            const int voff = (l15 * p.ldo + 4 * g) * 2;
+            const int voff = (pr * p.ldo + 4 * pg) * 2;
 #pragma unroll
             for (int i = i0; i < i0 + FH; ++i) {
                 const int mb = m0 + i * 16;
@@ -340,34 +371,76 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
                     u32x2 w;
-                    w[0] = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
-                    w[1] = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
-                    if (mb + 4 * g < p.M) __builtin_amdgcn_raw_buffer_store_b64(w, rsrcO, voff, ((bb * p.N + n0 + j * 16) * p.ldo + sb) * 2, 0);
+                    w[0] = perm(pack_bf16x2(acc[i][j][0], acc[i][j][1]));
+                    w[1] = perm(pack_bf16x2(acc[i][j][2], acc[i][j][3]));
+                    __builtin_amdgcn_raw_buffer_store_b64(w, rsrcO, mb + 4 * pg < p.M ? voff : OOB, ((bb * p.N + n0 + j * 16) * p.ldo + sb) * 2, 0);
                 }
             }
             return;
         }
-        const int voff = (l15 * p.ldo + 4 * g) * 2;
+        if (PP_ABL == 4) {
 #pragma unroll
-        for (int i = i0; i < i0 + FH; ++i) {
-            if constexpr (GEGLU) {
+            for (int i = i0; i < i0 + FH; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(acc[i][j]));
+            return;
+        }
+        // bf16 row-major output.  Output fragments (16 columns = 32 B per row) are taken in PAIRS: v_permlane16_swap exchanges
+        // the odd 16-lane rows of one fragment's register with the even rows of its neighbour's, after which lane (row, g) holds
+        // 16 contiguous bytes (g = 0: columns 0-7 of the first fragment, 1: 0-7 of the second, 2: 8-15 of the first, 3: 8-15 of the
+        // second); the wave permutation then puts the four 16-byte pieces of a row into neighbouring lanes (4 r + c, c = memory
+        // order): one 16-byte store per lane, 64 contiguous bytes per row (42 B/clk/CU).  An odd fragment left over goes out as
+        // 8 bytes per lane (runs of four lanes = 32 B).
+        if constexpr (GEGLU) {                        // half as many stores beside twice the arithmetic: the permutation does not pay here (measured)
+            const int voff = (l15 * p.ldo + 4 * g) * 2;
+#pragma unroll
+            for (int i = i0; i < i0 + FH; ++i)
 #pragma unroll
                 for (int j = 0; j + 1 < FN; j += 2) {
-                    const f32x2_t g01 = gelu_erf_fast2(f32x2_t{acc[i][j + 1][0], acc[i][j + 1][1]}) * f32x2_t{acc[i][j][0], acc[i][j][1]};
-                    const f32x2_t g23 = gelu_erf_fast2(f32x2_t{acc[i][j + 1][2], acc[i][j + 1][3]}) * f32x2_t{acc[i][j][2], acc[i][j][3]};
+                    const f32x2_t g01 = (PP_ABL == 3 ? f32x2_t{acc[i][j + 1][0], acc[i][j + 1][1]} : gelu_erf_fast2(f32x2_t{acc[i][j + 1][0], acc[i][j + 1][1]})) * f32x2_t{acc[i][j][0], acc[i][j][1]};
+                    const f32x2_t g23 = (PP_ABL == 3 ? f32x2_t{acc[i][j + 1][2], acc[i][j + 1][3]} : gelu_erf_fast2(f32x2_t{acc[i][j + 1][2], acc[i][j + 1][3]})) * f32x2_t{acc[i][j][2], acc[i][j][3]};
                     u32x2 w;
                     w[0] = pack_bf16x2(g01[0], g01[1]);
                     w[1] = pack_bf16x2(g23[0], g23[1]);
                     __builtin_amdgcn_raw_buffer_store_b64(w, rsrcO, voff, ((m0 + i * 16) * p.ldo + n0 / 2 + (j / 2) * 16) * 2, 0);
                 }
-            } else {
+            return;
+        }
+        constexpr int NOF = FN;                       // output fragments per fragment row
+        const int voff8 = (pr * p.ldo + 4 * pg) * 2;
+        const int voff16 = pr * p.ldo * 2 + pg * 16;
+        const int paddr16 = (pr + 16 * (((pg & 1) << 1) | (pg >> 1))) * 4;
+        const int ncol0 = n0;
 #pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    u32x2 w;
-                    w[0] = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
-                    w[1] = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
-                    __builtin_amdgcn_raw_buffer_store_b64(w, rsrcO, voff, ((m0 + i * 16) * p.ldo + n0 + j * 16) * 2, 0);
-                }
+        for (int i = i0; i < i0 + FH; ++i) {
+            auto outfrag = [&](int jo, unsigned& w0, unsigned& w1) {
+                w0 = pack_bf16x2(acc[i][jo][0], acc[i][jo][1]);
+                w1 = pack_bf16x2(acc[i][jo][2], acc[i][jo][3]);
+            };
+            const int row_off = PP_ABL == 5 ? ((m0 + i * 16) & 255) * p.ldo + ncol0 % 320 : (m0 + i * 16) * p.ldo + ncol0;      // 5: every tile to the same 256 x 320 window
+#pragma unroll
+            for (int jo = 0; jo + 1 < NOF; jo += 2) {
+                unsigned a0, a1, b0, b1;
+                outfrag(jo, a0, a1);
+                outfrag(jo + 1, b0, b1);
+                const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                u32x4 v;
+                v[0] = (unsigned)__builtin_amdgcn_ds_bpermute(paddr16, (int)s0[0]);
+                v[1] = (unsigned)__builtin_amdgcn_ds_bpermute(paddr16, (int)s1[0]);
+                v[2] = (unsigned)__builtin_amdgcn_ds_bpermute(paddr16, (int)s0[1]);
+                v[3] = (unsigned)__builtin_amdgcn_ds_bpermute(paddr16, (int)s1[1]);
+                if (PP_ABL == 8) asm volatile("" ::"v"(v));
+                else __builtin_amdgcn_raw_buffer_store_b128(v, rsrcO, voff16, (row_off + jo * 16) * 2, 0);
+            }
+            if constexpr (NOF % 2 == 1) {
+                unsigned a0, a1;
+                outfrag(NOF - 1, a0, a1);
+                u32x2 v;
+                v[0] = perm(a0);
+                v[1] = perm(a1);
+                if (PP_ABL == 8) asm volatile("" ::"v"(v));
+                else __builtin_amdgcn_raw_buffer_store_b64(v, rsrcO, voff8, (row_off + (NOF - 1) * 16) * 2, 0);
             }
         }
     };
@@ -382,22 +455,39 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     for (int i = 0; i < NA; ++i) issue_a(i, 0);
     advance();
     pp_wait_vmcnt<0>();
+    init_rows(first, I0_t{});
+    init_rows(first, I4_t{});
     pp_barrier();
     if (wr == 1) pp_barrier();                        // the lagging group starts one barrier late
 
     int c_tile = first, c_kt = 0, buf = 0;
     int p_tile = -1;                                  // tile whose high rows still sit in the accumulators (-1: none)
-    init_rows(c_tile, I0_t{});
-    init_rows(c_tile, I4_t{});
     for (int s = 0; s < S; ++s) {
         const bool more = s + 1 < S;                  // another K tile follows in this workgroup's stream: request it during this one
         const int nb = buf ^ 1;
 
         // ---- phase 1: low rows, k-substep 0 ----
         __builtin_amdgcn_sched_barrier(0);
-        read_a(buf, a_rd0, 0);
-        read_b(buf, b_rd0);
-        if (more) {
+        if (p_tile < 0) {
+            read_a(buf, a_rd0, 0);
+            read_b(buf, b_rd0);
+        }
+        if (p_tile >= 0) {
+            // first K tile of a new output tile (never the last K tile of the stream: nk >= 2).  The previous tile's high rows, final
+            // since the phase-4 MFMAs, leave now; its low rows left in that phase 4.  The VM counter is in order and counts stores:
+            // a wait that only needs loads OLDER than the stores names the stores (and the residual loads behind them) as allowed
+            // in flight, so no wait of the K loop ever sits behind a store's round trip.  Queue, oldest first:
+            //   A-high of this K tile | next tile's column vectors | low stores | high stores | B x NB1
+            // (the residual loads of init_rows are the compiler's: it drains the counter at their first use)
+            store_rows(p_tile, I4_t{});
+#pragma unroll
+            for (int i = 0; i < NB1; ++i) issue_b(i, nb);
+            pp_wait_vmcnt<NB1 + 2 * NST>();           // through A-high
+            init_rows(c_tile, I0_t{});
+            __builtin_amdgcn_sched_barrier(0);        // the fragment reads last: their registers are free for the epilogue's temporaries
+            read_a(buf, a_rd0, 0);
+            read_b(buf, b_rd0);
+        } else if (more) {
 #pragma unroll
             for (int i = 0; i < NB1; ++i) issue_b(i, nb);
             pp_wait_vmcnt<NB1>();                     // A-high of THIS K tile (requested in phase 4 of the previous one) has landed
@@ -416,8 +506,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
 #pragma unroll
             for (int i = NB1; i < FN; ++i) issue_b(i, nb);
         }
-        if (p_tile >= 0) {                            // first K tile of a new output tile: the previous tile's high rows leave now
-            store_rows(p_tile, I4_t{});
+        if (p_tile >= 0) {                            // the high rows of the new tile start
             init_rows(c_tile, I4_t{});
             p_tile = -1;
         }
@@ -449,12 +538,18 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
             advance();
             // B and A-low of the next K tile have landed (this phase's A-high pieces, and the next output tile's 6 column-vector
             // loads, may still be in flight)
-            if (switched) pp_wait_vmcnt<NA - 2 + (SPLIT ? 0 : 6)>();
+            if (PP_ABL == 9 && c_kt < 2) {}           // timing experiment: no wait in the two K tiles behind the stores (results garbage)
+            else if (switched) pp_wait_vmcnt<NA - 2 + (SPLIT ? 0 : 6)>();
             else pp_wait_vmcnt<NA - 2>();
         }
         if (c_kt == nk - 1) {                         // last K tile of the output tile: its low rows are final since phase 3
-            store_rows(c_tile, I0_t{});
-            if (more) init_rows(c_tile + G, I0_t{});
+#ifdef PP_TRACE
+            if (tid == 0) pp_trace[blockIdx.x * 64 + 2 * ((c_tile - first) / G & 31)] = __builtin_amdgcn_s_memrealtime();
+#endif
+            store_rows(c_tile, I0_t{});               // (they restart in phase 1 of the next K tile)
+#ifdef PP_TRACE
+            if (tid == 0) pp_trace[blockIdx.x * 64 + 2 * ((c_tile - first) / G & 31) + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();

@@ -95,7 +95,7 @@ int main(int argc, char** argv) {
     auto run_pp = [&](void* out, int bn) {
         ffn_igemm_desc e = d; e.out = out;
         const int nt = ((d.M + bm - 1) / bm) * (d.N / bn);
-        const int grid = nt < 256 ? nt : 256;
+        const int gmax = getenv("PP_GRID") ? atoi(getenv("PP_GRID")) : 256; const int grid = nt < gmax ? nt : gmax;
         const int lds = 2 * (bm + bn) * 128 + 12288;
 #define PPL(BM_, BN_, AM_, R_, G_) launch_pp(igemm_pp_kernel<BM_, BN_, AM_, R_, G_>, grid, 512, lds, e)
 #define PPB(BM_)                                                                                                   \
@@ -114,6 +114,25 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     run_pp(dO1, bn);
     CK(hipDeviceSynchronize());
+#ifdef PP_TRACE
+    {
+        run_pp(dO1, bn); CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> tr(256 * 64);
+        CK(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(pp_trace), tr.size() * 8));
+        unsigned long long t0 = ~0ull;
+        for (int w = 0; w < 256; ++w) if (tr[w * 64] && tr[w * 64] < t0) t0 = tr[w * 64];
+        for (int k = 0; k < 24; ++k) {
+            double mn = 1e30, mx = 0, dur = 0, dmx = 0; int n = 0;
+            for (int w = 0; w < 256; ++w) {
+                if (!tr[w * 64 + 2 * k]) continue;
+                const double a = (tr[w * 64 + 2 * k] - t0) * 0.01, b = (tr[w * 64 + 2 * k + 1] - t0) * 0.01;
+                mn = a < mn ? a : mn; mx = a > mx ? a : mx; dur += b - a; dmx = (b - a) > dmx ? b - a : dmx; ++n;
+            }
+            if (n) printf("tile %2d: low-row store section starts %.1f .. %.1f us after the first (spread %.1f), lasts %.2f us on average (max %.2f), %d workgroups\n", k, mn, mx, mx - mn, dur / n, dmx, n);
+        }
+        for (int w : {0, 1, 8, 9, 64, 65, 200}) { printf("wg %3d starts:", w); for (int k = 0; k < 8; ++k) printf(" %.1f", (tr[w * 64 + 2 * k] - t0) * 0.01); printf("\n"); }
+    }
+#endif
     std::vector<uint16_t> o0((long)d.M * d.N), o1((long)d.M * d.N);
     CK(hipMemcpy(o0.data(), dO0, o0.size() * 2, hipMemcpyDeviceToHost));
     CK(hipMemcpy(o1.data(), dO1, o1.size() * 2, hipMemcpyDeviceToHost));
