@@ -11,6 +11,7 @@
 #include "../../include/freefine_hip.h"
 #include "attention.h"
 #include "attention_pp.h"
+#include "attention_x.h"
 #include "elementwise.h"
 #include "igemm.h"
 #include "igemm_p8.h"
@@ -780,12 +781,49 @@ static void attn_bf16_choice(const ffn_attn_desc& d, bool* masks, bool* pp) {
     *masks = m;
     *pp = pp_on && d.D == 64 && d.Sk % 64 == 0 && d.S >= 128 && !uniform;
 }
+// cross attention against a short key sequence (attention_x.h): bf16, d = 64, Sk <= 96, ONE pass whose entries are all active and carry
+// no mask / selector / per-query weight.  Returns the key-fragment count of the instantiation (0: not this kernel).
+static int xattn_nkf(const ffn_attn_desc& d) {
+    static const bool on = [] { const char* e = getenv("FFN_ATTN_X"); return !(e && atoi(e) == 0); }();
+    if (!on || d.D != 64 || d.Sk > 96 || d.npass != 1 || d.ldo % 8 != 0) return 0;
+    int maxq = 0, maxkv = 0;
+    for (int b = 0; b < d.Bo; ++b) {
+        const ffn_attn_entry& e = d.e[b];
+        if ((e.w_const == 0.f && e.w_slope == 0.f) || e.kmask || e.qsel || e.wq) return 0;     // (flags only qualify a key mask)
+        if (e.w_slope != 0.f && !d.w_dev) return 0;
+        maxq = e.q_row > maxq ? e.q_row : maxq;
+        maxkv = e.kv_row > maxkv ? e.kv_row : maxkv;
+    }
+    const long lim = (1l << 31) - 65536;              // 32-bit byte offsets into every operand
+    if ((long)(maxq + 1) * d.S * d.ldq * 2 >= lim || (long)d.Bo * d.S * d.ldo * 2 >= lim || (long)(maxkv + 1) * d.Sk * d.ldk * 2 >= lim ||
+        (long)(maxkv + 1) * d.heads * 64 * d.ldvt * 2 >= lim)
+        return 0;
+    const int need = (d.Sk + 15) / 16;
+    return need <= 2 ? 2 : (need <= 5 ? 5 : 6);
+}
+static int launch_xattn(hipStream_t s, const ffn_attn_desc& d, int nkf) {
+    const int pairs = d.Bo * d.heads, nblk = (d.S + 31) / 32;
+    int wpp = (8 * device_cus()) / pairs;             // waves per (row, head): fill the chip's 8 waves per CU once
+    if (wpp < 1) wpp = 1;
+    if (wpp > nblk) wpp = nblk;
+    const int bpw = (nblk + wpp - 1) / wpp;
+    wpp = (nblk + bpw - 1) / bpw;
+    dim3 grid((pairs * wpp + 3) / 4);
+    if (nkf == 2) LAUNCH(xattn_kernel<2>, grid, dim3(256), 0, s, d, wpp, bpw);
+    else if (nkf == 5) LAUNCH(xattn_kernel<5>, grid, dim3(256), 0, s, d, wpp, bpw);
+    else LAUNCH(xattn_kernel<6>, grid, dim3(256), 0, s, d, wpp, bpw);
+    return check_launch("attn(cross)");
+}
 extern "C" int ffn_attn_kernel_name(int dtype, const ffn_attn_desc* d, char* buf, int len) {
     REQUIRE(d && buf && len > 0, "attn_kernel_name: null argument");
     int dp = 0, qf = 0;
     ffn_attn_variant(dtype, d->D, &dp, &qf);
     if (dtype == FFN_F32) {
         snprintf(buf, len, "void attn_kernel<float, %d, %d, %d, 1, true>(ffn_attn_desc)", dp, qf, dp == 160 ? 32 : 64);
+        return FFN_OK;
+    }
+    if (const int nkf = xattn_nkf(*d)) {
+        snprintf(buf, len, "void xattn_kernel<%d>(ffn_attn_desc, int, int)", nkf);
         return FFN_OK;
     }
     bool masks, pp;
@@ -814,6 +852,7 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
         if (D <= 80) return launch_attn<float, 80, 2>(s, *d);
         if (D <= 160) return launch_attn<float, 160, 1, 32>(s, *d);
     } else {
+        if (const int nkf = xattn_nkf(*d)) return launch_xattn(s, *d, nkf);
         bool masks, pp;
         attn_bf16_choice(*d, &masks, &pp);
         if (pp) {

@@ -172,6 +172,38 @@ def test_attention_plain(gpu, dtype, S, Sk, heads, D):
         assert relerr(out[b], ref) < tol(dtype)
 
 
+@pytest.mark.parametrize("S,Sk,heads,ldvt", [(4096, 77, 5, 80), (1024, 77, 10, 80), (100, 77, 2, 80), (256, 20, 3, 24), (72, 96, 1, 96), (40, 81, 2, 88)])
+def test_cross_attention_short_keys(gpu, S, Sk, heads, ldvt):
+    """xattn_kernel (bf16, d = 64, Sk <= 96, one unmasked pass): K / V^T held in registers per wave, query blocks of 32 streamed.
+    Row maps (q_row / kv_row, as in row-deduplicated CFG batches), a device-scalar weight, ragged S, Sk below / at / above the fragment
+    counts the kernel is instantiated for (2, 5, 6 fragments of 16 keys), V^T padding up to ldvt filled with huge finite values."""
+    import ctypes
+    from freefine_amd import _lib, ops
+    g = torch.Generator().manual_seed(S + Sk)
+    dtype, D = torch.bfloat16, 64
+    Bq, Bk, Cc = 3, 2, heads * D
+    q = rnd((Bq, S, Cc), dtype, gpu, g)
+    k = rnd((Bk, Sk, Cc), dtype, gpu, g)
+    v = rnd((Bk, Sk, Cc), dtype, gpu, g)
+    vt = torch.full((Bk, Cc, ldvt), 3.0e38, dtype=dtype, device=gpu)
+    vt[:, :, :Sk] = v.transpose(1, 2)
+    scale = D ** -0.5
+    cg = torch.tensor([0.25], device=gpu)
+    rows = [ops.AttnEntrySpec(2, 1, 1.0, 0.0), ops.AttnEntrySpec(0, 0, 0.5, 2.0), ops.AttnEntrySpec(1, 1, 1.0, 0.0), ops.AttnEntrySpec(2, 0, 1.0, 0.0)]
+    out = ops.attention(q, k, vt, heads, scale, [rows], Sk=Sk, w_dev=cg)
+    d = _lib.AttnDesc()
+    d.Bo, d.S, d.Sk, d.heads, d.D, d.npass, d.ldo, d.w_dev = 4, S, Sk, heads, D, 1, Cc, cg.data_ptr()
+    for b, sp in enumerate(rows):
+        d.e[b].q_row, d.e[b].kv_row, d.e[b].w_const, d.e[b].w_slope = sp.q_row, sp.kv_row, sp.w_const, sp.w_slope
+    name = ctypes.create_string_buffer(160)
+    _lib.load().ffn_attn_kernel_name(1, ctypes.byref(d), name, 160)
+    assert b"xattn_kernel" in name.value, name.value
+    for b, sp in enumerate(rows):
+        wgt = sp.w_const + sp.w_slope * 0.25
+        ref = wgt * ref_attention(q[sp.q_row].double().cpu(), k[sp.kv_row].double().cpu(), v[sp.kv_row].double().cpu(), heads, scale)
+        assert relerr(out[b], ref) < tol(dtype), (b, relerr(out[b], ref))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("S,heads,D", [(192, 5, 64), (200, 8, 40), (144, 4, 80), (136, 2, 160)])
 def test_attention_tca_edit(gpu, dtype, S, heads, D):
