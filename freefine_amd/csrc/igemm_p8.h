@@ -175,7 +175,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
                 a_off[i] = m < p.M ? (PP_ABL == 10 ? m & 255 : m) * (p.lda * 2) + csrc * 16 : OOB;      // 10: every tile reads the same 256 rows (L2-hot A; results garbage)
             } else {
                 const int hw = p.Hout * p.Wout;
-                const int b = m / hw, rem = m - b * hw;
+                const int ma = PP_ABL == 10 ? (m & 255) : m;       // 10: every tile reads the same 256 pixels (L2-hot A; results garbage)
+                const int b = ma / hw, rem = ma - b * hw;
                 const int yo = rem / p.Wout, xo = rem - yo * p.Wout;
                 const int y0 = yo * p.stride - p.pad, x0 = xo * p.stride - p.pad;       // in (nearest-2x upsampled) input coordinates
                 a_off[i] = ((b * p.Hin + (y0 >> p.upsample)) * p.Win + (x0 >> p.upsample)) * (p.Cin * 2) + csrc * 16;
