@@ -122,7 +122,9 @@ typedef struct ffn_attn_desc {
 int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d);
 /* bf16 launches with D = 64, Sk % 64 == 0, S >= 128 and no degenerate (uniform-softmax) entry run attn_pp_kernel (attention_pp.h:
  * software-pipelined, 8 waves in two alternating groups); everything else attn_kernel (attention.h).  Same results up to fp32
- * summation order.  FFN_ATTN_PP=0 in the environment forces attn_kernel. */
+ * summation order.  FFN_ATTN_PP=0 in the environment forces attn_kernel.
+ * bf16 launches with D = 64, Sk <= 96 and ONE pass whose entries carry no key mask / selector / per-query weight (the text
+ * cross-attention) run xattn_kernel (attention_x.h: K and V^T of a (row, head) in a wave's registers); FFN_ATTN_X=0 disables it. */
 /* padded head dim / query fragments per wave of the instantiation ffn_attn dispatches for head dim D */
 int ffn_attn_variant(int dtype, int D, int* dp, int* qf);
 /* the kernel instantiation ffn_attn launches for this problem, spelled like rocprofv3's kernel trace */
