@@ -7,7 +7,7 @@
 // softmax (~130 VALU incl. 32 v_exp), 20 PV MFMAs, vmcnt(0), barrier]: the MFMA chains sit at both ends of a long VALU stretch, and
 // whether the SIMD's other wave fills the gaps is left to chance (measured: 33 % MFMA busy, 743 TFLOP/s at S = 4096).  Here:
 //   * 8 waves per workgroup (256 queries, 32 per wave), ONE workgroup per CU; waves 4-7 run one barrier behind waves 0-3, so the
-//     two waves of a SIMD alternate: one issues its MFMA segment (s_setprio 1) while the other runs its VALU segment;
+//     two waves of a SIMD alternate: one issues its MFMA segment while the other runs its VALU segment (at s_setprio 1);
 //   * the key loop is software-pipelined so that a segment is either all-MFMA or all-VALU:
 //       V segment t:  softmax of S(t) -> P(t);  fragment reads of V^T(t) and K(t+1);  LDS-DMA requests of K(t+3), mask(t+3), V^T(t+2)
 //       M segment t:  O += V^T(t) P(t) (20 MFMAs);  S(t+1) = K(t+1) Q^T (16 MFMAs, + 8 when the pass carries a key mask)
@@ -23,8 +23,14 @@
 #pragma once
 #include "attention.h"
 
+#ifndef ATTPP_PRIO
+// 2 (shipped): the softmax (V) segment runs at s_setprio 1 and the MFMA segment at 0 -- the MFMA chain is paced by the matrix pipe and
+// loses nothing, while a prioritised MFMA wave takes the issue slots the partner's dependent exp -> cvt chains need (measured at
+// S = 4096, 16 rows: 353 -> 335 us one pass, 746 -> 729 us two passes; S = 1024: 73.8 -> 70.3 us); 1: the MFMA segment at 1; 0: none
+#define ATTPP_PRIO 2
+#endif
 #ifndef ATTPP_ABL
-#define ATTPP_ABL 0   // timing-only ablation builds of tools/native/attn_bench.hip: 1 no LDS-DMA, 2 no counted waits, 3 no softmax, 4 no MFMA, 5 no fragment reads
+#define ATTPP_ABL 0   // timing-only ablation builds of tools/native/attn_bench.hip: 1 no LDS-DMA, 2 no counted waits, 3 no softmax, 4 no MFMA, 5 no fragment reads, 6 half the MFMAs
 #endif
 template <int N>
 __device__ __forceinline__ void attpp_wait_vmcnt() {
@@ -206,7 +212,10 @@ __global__ __launch_bounds__(512) void attn_pp_kernel(const AttnParams p) {
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                    for (int f = 0; f < QF; ++f) DT<T>::mma(ka[s][tt], qf[f][s], st[tt][f]);
+                    for (int f = 0; f < QF; ++f) {
+                        if (ATTPP_ABL == 6 && f) continue;      // timing experiment: half the MFMA issues (results garbage)
+                        DT<T>::mma(ka[s][tt], qf[f][s], st[tt][f]);
+                    }
         };
         auto mfma_pv = [&]() {
             const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
@@ -217,7 +226,10 @@ __global__ __launch_bounds__(512) void attn_pp_kernel(const AttnParams p) {
 #pragma unroll
                 for (int i = 0; i < FD; ++i)
 #pragma unroll
-                    for (int f = 0; f < QF; ++f) DT<T>::mma(va[c][i], pb[c][f], o[i][f]);
+                    for (int f = 0; f < QF; ++f) {
+                        if (ATTPP_ABL == 6 && f) continue;
+                        DT<T>::mma(va[c][i], pb[c][f], o[i][f]);
+                    }
             }
         };
         auto softmax = [&]() {                                  // S(t) -> P(t), same arithmetic as attn_kernel::tile_fast
@@ -271,9 +283,8 @@ __global__ __launch_bounds__(512) void attn_pp_kernel(const AttnParams p) {
         read_k(0);
         __builtin_amdgcn_sched_barrier(0);
         attpp_barrier();
-        __builtin_amdgcn_s_setprio(1);
         mfma_qk();
-        __builtin_amdgcn_s_setprio(0);
+        if (ATTPP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
         attpp_barrier();
 
@@ -295,17 +306,20 @@ __global__ __launch_bounds__(512) void attn_pp_kernel(const AttnParams p) {
             __builtin_amdgcn_sched_barrier(0);
             attpp_barrier();
             // ---- M segment ----
-            __builtin_amdgcn_s_setprio(1);
+            if (ATTPP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+            if (ATTPP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
             if (ATTPP_ABL != 4) {
                 mfma_pv();
                 mfma_qk();
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (ATTPP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+            if (ATTPP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
             __builtin_amdgcn_sched_barrier(0);
             attpp_barrier();
         }
         // drain: nothing of this pass may still be landing when the next pass (or another workgroup's prologue) re-uses the rings,
         // and every fragment read of this pass is retired two barriers before the next request
+        __builtin_amdgcn_s_setprio(0);
         attpp_wait_vmcnt<0>();
         attpp_barrier();
         attpp_barrier();

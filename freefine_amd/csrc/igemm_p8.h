@@ -46,6 +46,9 @@
 #include <type_traits>
 #include "igemm.h"
 
+#ifndef PP_PRIO
+#define PP_PRIO 1     // 1: MFMA sections at s_setprio 1 (shipped); 0: no priorities; 2: load sections at s_setprio 1
+#endif
 #ifndef PP_ABL
 #define PP_ABL 0      // timing-only ablation builds of tools/native/pp_bench.hip: 1 = no global loads, 2 = no counted waits, 3 = GEGLU without the GELU, 4 = no epilogue stores (results garbage)
 #endif
@@ -256,7 +259,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     };
     auto mfma_rows = [&](auto I0) {
         constexpr int i0 = decltype(I0)::value;
-        __builtin_amdgcn_s_setprio(1);
+        if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        if (PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int i = 0; i < FH; ++i)
 #pragma unroll
@@ -264,7 +268,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
                 if constexpr (TRANS) DT<T>::mma(fa[i], fb[j], acc[i0 + i][j]);      // C[m = 4g + r][n = l15]
                 else DT<T>::mma(fb[j], fa[i], acc[i0 + i][j]);                      // C[m = l15][n = 4g + r]
             }
-        __builtin_amdgcn_s_setprio(0);
+        if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if (PP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
     };
     typedef std::integral_constant<int, 0> I0_t;
     typedef std::integral_constant<int, FH> I4_t;
