@@ -783,17 +783,22 @@ static void attn_bf16_choice(const ffn_attn_desc& d, bool* masks, bool* pp) {
 }
 // cross attention against a short key sequence (attention_x.h): bf16, d = 64, Sk <= 96, ONE pass whose entries are all active and carry
 // no mask / selector / per-query weight.  Returns the key-fragment count of the instantiation (0: not this kernel).
-static int xattn_nkf(const ffn_attn_desc& d) {
+// *multi = 1: the launch has several passes, skipped entries or per-query weights -> xattn_mp_kernel (K / V^T fragment images in LDS).
+static int xattn_nkf(const ffn_attn_desc& d, int* multi = nullptr) {
     static const bool on = [] { const char* e = getenv("FFN_ATTN_X"); return !(e && atoi(e) == 0); }();
-    if (!on || d.D != 64 || d.Sk > 96 || d.npass != 1 || d.ldo % 8 != 0) return 0;
-    int maxq = 0, maxkv = 0;
-    for (int b = 0; b < d.Bo; ++b) {
-        const ffn_attn_entry& e = d.e[b];
-        if ((e.w_const == 0.f && e.w_slope == 0.f) || e.kmask || e.qsel || e.wq) return 0;     // (flags only qualify a key mask)
-        if (e.w_slope != 0.f && !d.w_dev) return 0;
-        maxq = e.q_row > maxq ? e.q_row : maxq;
-        maxkv = e.kv_row > maxkv ? e.kv_row : maxkv;
-    }
+    if (!on || d.D != 64 || d.Sk > 96 || d.ldo % 8 != 0) return 0;
+    int maxq = 0, maxkv = 0, mp = d.npass != 1;
+    for (int pi = 0; pi < d.npass; ++pi)
+        for (int b = 0; b < d.Bo; ++b) {
+            const ffn_attn_entry& e = d.e[pi * FFN_ATT_MAXB + b];
+            if (e.w_const == 0.f && e.w_slope == 0.f) { mp = 1; continue; }
+            if (e.kmask || e.qsel) return 0;                    // (flags only qualify a key mask)
+            if (e.w_slope != 0.f && !d.w_dev) return 0;
+            if (e.wq) mp = 1;
+            maxq = e.q_row > maxq ? e.q_row : maxq;
+            maxkv = e.kv_row > maxkv ? e.kv_row : maxkv;
+        }
+    if (multi) *multi = mp;
     const long lim = (1l << 31) - 65536;              // 32-bit byte offsets into every operand
     if ((long)(maxq + 1) * d.S * d.ldq * 2 >= lim || (long)d.Bo * d.S * d.ldo * 2 >= lim || (long)(maxkv + 1) * d.Sk * d.ldk * 2 >= lim ||
         (long)(maxkv + 1) * d.heads * 64 * d.ldvt * 2 >= lim)
@@ -801,8 +806,23 @@ static int xattn_nkf(const ffn_attn_desc& d) {
     const int need = (d.Sk + 15) / 16;
     return need <= 2 ? 2 : (need <= 5 ? 5 : 6);
 }
-static int launch_xattn(hipStream_t s, const ffn_attn_desc& d, int nkf) {
+static int launch_xattn(hipStream_t s, const ffn_attn_desc& d, int nkf, int multi) {
     const int pairs = d.Bo * d.heads, nblk = (d.S + 31) / 32;
+    if (multi) {                                      // one workgroup of 4 waves per (row, head, chunk): fragment images of all passes in LDS
+        int wpp = (8 * device_cus()) / pairs / 4;     // workgroups per (row, head)
+        if (wpp < 1) wpp = 1;
+        if (wpp > (nblk + 3) / 4) wpp = (nblk + 3) / 4;
+        const int bpw = (nblk + 4 * wpp - 1) / (4 * wpp);
+        wpp = (nblk + 4 * bpw - 1) / (4 * bpw);
+        const int nfr = nkf * 2 + 4 * ((nkf + 1) / 2);
+        const int lds = d.npass * nfr * 1024;
+        dim3 grid(pairs * wpp);
+        int rc;
+        if (nkf == 2) { if ((rc = set_lds(xattn_mp_kernel<2>, lds))) return rc; LAUNCH(xattn_mp_kernel<2>, grid, dim3(256), lds, s, d, wpp, bpw); }
+        else if (nkf == 5) { if ((rc = set_lds(xattn_mp_kernel<5>, lds))) return rc; LAUNCH(xattn_mp_kernel<5>, grid, dim3(256), lds, s, d, wpp, bpw); }
+        else { if ((rc = set_lds(xattn_mp_kernel<6>, lds))) return rc; LAUNCH(xattn_mp_kernel<6>, grid, dim3(256), lds, s, d, wpp, bpw); }
+        return check_launch("attn(cross, multi-pass)");
+    }
     int wpp = (8 * device_cus()) / pairs;             // waves per (row, head): fill the chip's 8 waves per CU once
     if (wpp < 1) wpp = 1;
     if (wpp > nblk) wpp = nblk;
@@ -822,8 +842,9 @@ extern "C" int ffn_attn_kernel_name(int dtype, const ffn_attn_desc* d, char* buf
         snprintf(buf, len, "void attn_kernel<float, %d, %d, %d, 1, true>(ffn_attn_desc)", dp, qf, dp == 160 ? 32 : 64);
         return FFN_OK;
     }
-    if (const int nkf = xattn_nkf(*d)) {
-        snprintf(buf, len, "void xattn_kernel<%d>(ffn_attn_desc, int, int)", nkf);
+    int multi = 0;
+    if (const int nkf = xattn_nkf(*d, &multi)) {
+        snprintf(buf, len, "void %s<%d>(ffn_attn_desc, int, int)", multi ? "xattn_mp_kernel" : "xattn_kernel", nkf);
         return FFN_OK;
     }
     bool masks, pp;
@@ -852,7 +873,8 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
         if (D <= 80) return launch_attn<float, 80, 2>(s, *d);
         if (D <= 160) return launch_attn<float, 160, 1, 32>(s, *d);
     } else {
-        if (const int nkf = xattn_nkf(*d)) return launch_xattn(s, *d, nkf);
+        int multi = 0;
+        if (const int nkf = xattn_nkf(*d, &multi)) return launch_xattn(s, *d, nkf, multi);
         bool masks, pp;
         attn_bf16_choice(*d, &masks, &pp);
         if (pp) {

@@ -204,6 +204,45 @@ def test_cross_attention_short_keys(gpu, S, Sk, heads, ldvt):
         assert relerr(out[b], ref) < tol(dtype), (b, relerr(out[b], ref))
 
 
+@pytest.mark.parametrize("S,Sk,heads", [(4096, 77, 5), (1024, 77, 10), (100, 77, 2), (64, 30, 1)])
+def test_cross_attention_short_keys_multi_pass(gpu, S, Sk, heads):
+    """xattn_mp_kernel: the guided pass's local cross-attention (two passes, per-query blend weights, skipped entries, a row that no
+    pass contributes to) against the fp64 statement; K / V^T fragment images of every pass in LDS."""
+    import ctypes
+    from freefine_amd import _lib, ops
+    g = torch.Generator().manual_seed(7 * S + Sk)
+    dtype, D = torch.bfloat16, 64
+    B, Cc = 4, heads * D
+    q = rnd((B, S, Cc), dtype, gpu, g)
+    k = rnd((B, Sk, Cc), dtype, gpu, g)
+    v = rnd((B, Sk, Cc), dtype, gpu, g)
+    vt = ops.transpose(v, ld_dst=(Sk + 7) // 8 * 8)
+    scale = D ** -0.5
+    f = torch.rand(S, generator=g).to(gpu)
+    omf = 1.0 - f
+    p0 = [ops.AttnEntrySpec(0, 0), ops.AttnEntrySpec(1, 1), ops.AttnEntrySpec(2, 2, wq=f), None, ops.AttnEntrySpec(1, 3, 0.5, 0.0)]
+    p1 = [None, None, ops.AttnEntrySpec(0, 0, wq=omf), None, ops.AttnEntrySpec(3, 2, 0.25, 0.0, wq=f)]
+    out = ops.attention(q, k, vt, heads, scale, [p0, p1], Sk=Sk)
+    d = _lib.AttnDesc()
+    d.Bo, d.S, d.Sk, d.heads, d.D, d.npass, d.ldo = 5, S, Sk, heads, D, 2, Cc
+    for pi, rows in enumerate((p0, p1)):
+        for b, sp in enumerate(rows):
+            e = d.e[pi * _lib.ATT_MAXB + b]
+            if sp is not None:
+                e.q_row, e.kv_row, e.w_const, e.w_slope = sp.q_row, sp.kv_row, sp.w_const, sp.w_slope
+                e.wq = 0 if sp.wq is None else sp.wq.data_ptr()
+    name = ctypes.create_string_buffer(160)
+    _lib.load().ffn_attn_kernel_name(1, ctypes.byref(d), name, 160)
+    assert b"xattn_mp_kernel" in name.value, name.value
+    A = lambda qi, ki: ref_attention(q[qi].double().cpu(), k[ki].double().cpu(), v[ki].double().cpu(), heads, scale)
+    fd, od = f.double().cpu()[:, None], omf.double().cpu()[:, None]
+    refs = [A(0, 0), A(1, 1), fd * A(2, 2) + od * A(0, 0), torch.zeros(S, Cc, dtype=torch.float64), 0.5 * A(1, 3) + 0.25 * fd * A(3, 2)]
+    scale_ref = max(r.abs().max().item() for r in refs)
+    for b, ref in enumerate(refs):
+        err = (out[b].double().cpu() - ref).abs().max().item() / scale_ref
+        assert err < tol(dtype), (b, err)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("S,heads,D", [(192, 5, 64), (200, 8, 40), (144, 4, 80), (136, 2, 160)])
 def test_attention_tca_edit(gpu, dtype, S, heads, D):

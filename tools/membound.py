@@ -58,6 +58,17 @@ for hw, C in ((64, 320), (32, 640), (16, 1280)):
     k = rnd(B, 77, C)
     vtx = rnd(B, C, 80)
     report("cross-attention Sk=77", timeit(lambda: ops.attention(x, k, vtx, heads, 0.125, Sk=77, out=o)), 4 * M * C)
+    fw = torch.rand(S, generator=g).to(dev)
+    ofw = 1.0 - fw
+    def local_passes():                       # the guided pass's local cross-attention over images of 3 physical rows [u_e, ref, c_e]
+        p0, p1 = [], []
+        for r0 in range(0, B - 2, 3):
+            p0 += [ops.AttnEntrySpec(r0, r0), ops.AttnEntrySpec(r0 + 1, r0 + 1), ops.AttnEntrySpec(r0 + 2, r0 + 2, wq=fw)]
+            p1 += [None, None, ops.AttnEntrySpec(r0, r0, wq=ofw)]
+        return [p0, p1]
+    lp = local_passes()
+    nb = len(lp[0])
+    report("cross-attention Sk=77, local edit (2 passes, wq)", timeit(lambda: ops.attention(x, k, vtx, heads, 0.125, lp, Sk=77, out=o[:nb])), 4 * nb * S * C + 2 * (nb // 3) * S * C)
     w4 = ops.pack_linear(rnd(C, 4 * C, scale=(4 * C) ** -0.5), dt)
     h = rnd(B, S, 4 * C)
     report("linear 4C->C + bias + residual (FF out)", timeit(lambda: ops.linear(h, w4, bias, out=o, residual=r)), 2 * M * 4 * C + 4 * M * C)
