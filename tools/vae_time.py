@@ -1,0 +1,43 @@
+"""Time of the VAE bracket of one 16-image edit batch (encode 32 images: coarse + original; decode 16 latents), bf16, with the per-kernel
+event profile of the decode.  python tools/vae_time.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from freefine_amd import ops  # noqa: E402
+from freefine_amd.config import VAEConfig  # noqa: E402
+from freefine_amd.vae import HipVAE  # noqa: E402
+from freefine_amd.weights import synthetic_state, vae_param_shapes  # noqa: E402
+
+dev = torch.device("cuda:0")
+cfg = VAEConfig.preset("sd")
+vae = HipVAE(cfg, synthetic_state(vae_param_shapes(cfg), 1), torch.bfloat16, dev)
+img = torch.randint(0, 256, (16, 512, 512, 3), dtype=torch.uint8, device=dev)
+lat = torch.randn(16, 4, 64, 64, device=dev)
+
+
+def timeit(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+te = timeit(lambda: vae.encode_mean_scaled(img_u8=img))
+td = timeit(lambda: vae.decode_image(lat))
+print(f"encode 16 images: {te:.1f} ms, decode 16 latents: {td:.1f} ms -> VAE bracket of a 16-image batch (2 encodes + 1 decode): {2 * te + td:.1f} ms")
+for name, fn in (("encode", lambda: vae.encode_mean_scaled(img_u8=img)), ("decode", lambda: vae.decode_image(lat))):
+    ops.profile_begin()
+    fn()
+    prof = ops.profile_end()
+    rows = sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:8]
+    print(name)
+    for k, v in rows:
+        print(f"   {v['total_ms']:8.2f} ms  {v['calls']:4d} calls  {v['flops'] / max(v['total_ms'], 1e-9) / 1e9:7.0f} TFLOP/s  {k[:110]}")
