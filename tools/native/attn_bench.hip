@@ -72,5 +72,16 @@ int main(int argc, char** argv) {
         }
         printf("round %d: attn_kernel %.1f us (%.0f TF)   attn_pp %.1f us (%.0f TF)\n", round, t[0], flops / t[0] * 1e-6, t[1], flops / t[1] * 1e-6);
     }
+    {   // determinism = race detector: two runs of the ping-pong kernel must agree bit for bit (20 pairs)
+        std::vector<uint16_t> r0(n), r1(n);
+        long bad = 0;
+        for (int it = 0; it < 20; ++it) {
+            CK(hipMemset(do0, 0xff, n * 2)); CK(hipMemset(do1, 0xff, n * 2));
+            run_all(1, do0); run_all(1, do1); CK(hipDeviceSynchronize());
+            CK(hipMemcpy(r0.data(), do0, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), do1, n * 2, hipMemcpyDeviceToHost));
+            if (memcmp(r0.data(), r1.data(), n * 2)) ++bad;
+        }
+        printf("determinism: %ld of 20 run pairs differ\n", bad);
+    }
     return 0;
 }

@@ -164,5 +164,16 @@ int main(int argc, char** argv) {
         printf("round %d: 128x320 %.1f us (%.0f TF)   256x256/16w %.1f us (%.0f TF)   pp%dx%d %.1f us (%.0f TF)\n", round, t[0], flops / t[0] * 1e-6, t[1],
                flops / t[1] * 1e-6, bm, bn, t[2], flops / t[2] * 1e-6);
     }
+    {   // determinism = race detector: the kernel's arithmetic order is fixed, so two runs must agree bit for bit (20 pairs, back to back)
+        std::vector<uint16_t> r0((long)d.M * d.ldo), r1((long)d.M * d.ldo);
+        long bad = 0;
+        for (int it = 0; it < 20; ++it) {
+            CK(hipMemset(dO0, 0xff, (long)d.M * d.N * 2)); CK(hipMemset(dO1, 0xff, (long)d.M * d.N * 2));
+            run_pp(dO0, bn); run_pp(dO1, bn); CK(hipDeviceSynchronize());
+            CK(hipMemcpy(r0.data(), dO0, r0.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), dO1, r1.size() * 2, hipMemcpyDeviceToHost));
+            if (memcmp(r0.data(), r1.data(), r0.size() * 2)) ++bad;
+        }
+        printf("determinism: %ld of 20 run pairs differ\n", bad);
+    }
     return 0;
 }
