@@ -464,6 +464,47 @@ def test_splitk_conv_and_linear(gpu, dtype, splitk):
     assert out.dtype == torch.float32 and relerr(out, a.double() @ wl.double().t()) < tol(dtype)
 
 
+def test_kernels_are_deterministic(gpu):
+    """Race detector for the software-pipelined kernels (counted waits, LDS-DMA in flight across barriers, epilogue stores named in the
+    waits): their arithmetic order is fixed, so repeated launches on the same operands must agree bit for bit -- on shapes with many
+    tiles per workgroup, every epilogue option, both attention kernels and the cross-attention kernels."""
+    from freefine_amd import ops
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    def same(fn, n=6):
+        ref = fn().clone()
+        torch.cuda.synchronize()
+        for _ in range(n):
+            assert torch.equal(fn(), ref)
+    B, H, Cin, Cout = 24, 64, 320, 320
+    x, w = rnd((B, H * H, Cin), dt, gpu, g), ops.pack_conv3x3(rnd((Cout, Cin, 3, 3), dt, gpu, g, (9 * Cin) ** -0.5), dt)
+    b, rb, r = rnd((Cout,), torch.float32, gpu, g), rnd((B, Cout), torch.float32, gpu, g), rnd((B, H * H, Cout), dt, gpu, g)
+    same(lambda: ops.conv3x3(x, w, b, B, H, H, Cin, rowbias=rb))
+    same(lambda: ops.conv3x3(x, w, b, B, H, H, Cin, residual=r))
+    xm = x.reshape(B * H * H, Cin)
+    wl, w4 = ops.pack_linear(rnd((Cout, Cin), dt, gpu, g, Cin ** -0.5), dt), ops.pack_linear(rnd((Cout, 4 * Cin), dt, gpu, g, (4 * Cin) ** -0.5), dt)
+    same(lambda: ops.linear(xm, wl, b))
+    same(lambda: ops.linear(xm, wl, b, residual=r.reshape(-1, Cout)))
+    wg, bg = ops.pack_geglu(rnd((8 * Cin, Cin), dt, gpu, g, Cin ** -0.5), rnd((8 * Cin,), torch.float32, gpu, g), dt)
+    hgl = ops.linear(xm, wg, bg, K=Cin, geglu=True)
+    same(lambda: ops.linear(xm, wg, bg, K=Cin, geglu=True), 3)
+    same(lambda: ops.linear(hgl, w4, b, residual=r.reshape(-1, Cout)), 3)
+    same(lambda: ops.linear(x, wl, None, rows_per_batch=H * H, transposed_ld=H * H), 3)
+    S, heads = 4096, 5
+    q, k, vt = rnd((4, S, Cin), dt, gpu, g), rnd((4, S, Cin), dt, gpu, g), rnd((4, Cin, S), dt, gpu, g)
+    km = (torch.rand(S, generator=g) > 0.6).to(torch.uint8).to(gpu)
+    qs = (torch.rand(S, generator=g) > 0.5).to(torch.uint8).to(gpu)
+    cg = torch.tensor([0.4], device=gpu)
+    tca = [[ops.AttnEntrySpec(i, i | 1, 0.0, 1.0, kmask=km, qsel=qs, flags=1) for i in range(4)], [ops.AttnEntrySpec(i, i, 1.0, -1.0) for i in range(4)]]
+    same(lambda: ops.attention(q, k, vt, heads, 0.125), 3)
+    same(lambda: ops.attention(q, k, vt, heads, 0.125, tca, w_dev=cg), 3)
+    kt, vtt = rnd((4, 77, Cin), dt, gpu, g), rnd((4, Cin, 80), dt, gpu, g)
+    fw = torch.rand(S, generator=g).to(gpu)
+    loc = [[ops.AttnEntrySpec(0, 0), ops.AttnEntrySpec(1, 1), ops.AttnEntrySpec(2, 2, wq=fw), ops.AttnEntrySpec(1, 1)], [None, None, ops.AttnEntrySpec(0, 0, wq=1.0 - fw), None]]
+    same(lambda: ops.attention(q, kt, vtt, heads, 0.125, Sk=77), 3)
+    same(lambda: ops.attention(q, kt, vtt, heads, 0.125, loc, Sk=77), 3)
+
+
 def test_every_bf16_igemm_configuration(gpu):
     """ffn_igemm picks (tile, K-split) per shape by timing; force EVERY bf16 configuration in turn (incl. the 256x256 / 128x320
     tiles, the persistent tile walk and the weight-stationary kernels) on shapes where it is valid and check the result."""
