@@ -906,11 +906,14 @@ extern "C" int ffn_gn_nchunk(int HW) {
 }
 // one fused launch (statistics + normalise + SiLU by the workgroup that owns a (row, group) slice) or stats + finalize + apply?
 // Measured (tools/bench_kernels.py --only norm): the fused kernel reads 20-120 byte per-pixel group segments, so it only wins while
-// the tensor is small enough for launch latency to dominate -- up to 16x16 positions at any batch, 32x32 below ~3M elements.
+// the tensor is small enough for launch latency to dominate -- up to 8x8 positions at any batch, 16x16 up to 32 rows (at 48 rows,
+// the image-batched guided pass, the three-launch form is 7-18 % faster there: 34.9 vs 37.5 us at C = 1280, 56.6 vs 66.1 at 2560),
+// 32x32 below ~3M elements.
 extern "C" int ffn_gn_fused(int B, int HW, int C, int G) {
     const long slice = (long)HW * (C / (G > 0 ? G : 1));
     if (slice > 131072) return 0;
-    if (HW <= 256) return 1;
+    if (HW <= 64) return 1;
+    if (HW <= 256) return B <= 32 ? 1 : 0;
     return (HW <= 1024 && (long)B * HW * C <= 3000000l) ? 1 : 0;
 }
 extern "C" int ffn_groupnorm(void* stream, int dtype, const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C,
