@@ -1043,9 +1043,9 @@ extern "C" int ffn_nhwc_to_nchw_f32(void* stream, const float* src, float* dst, 
 extern "C" int ffn_concat(void* stream, int dtype, const void* a, const void* b, void* out, long rows, int C1, int C2) {
     REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "concat: bad dtype");
     const int epc = dtype == FFN_F32 ? 4 : 8;
-    REQUIRE(a && b && out && C1 % epc == 0 && C2 % epc == 0 && aligned16(a) && aligned16(b) && aligned16(out), "concat: bad arguments");
+    REQUIRE(b && out && C1 % epc == 0 && C2 % epc == 0 && aligned16(a) && aligned16(b) && aligned16(out), "concat: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const long n = rows * ((C1 + C2) / epc);
+    const long n = rows * ((a ? C1 + C2 : C2) / epc);     // a == NULL: out[:, :C1] is already in place, only b moves
     if (dtype == FFN_F32) LAUNCH(concat_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)out, rows, C1, C2);
     else LAUNCH(concat_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16*)a, (const bf16*)b, (bf16*)out, rows, C1, C2);
     return check_launch("concat");

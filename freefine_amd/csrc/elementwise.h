@@ -77,16 +77,18 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const float* __re
     }
 }
 
-// out[r, 0:C1] = a[r, :], out[r, C1:C1+C2] = b[r, :]   (skip-connection concat of the UNet up path), 16-byte chunks
+// out[r, 0:C1] = a[r, :], out[r, C1:C1+C2] = b[r, :]   (skip-connection concat of the UNet up path), 16-byte chunks.
+// a == nullptr: the left block is already in place (its producer wrote it there with ldo = C1 + C2): only b is copied.
 template <typename T>
 __global__ __launch_bounds__(256) void concat_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
                                                      long rows, int C1, int C2) {
     constexpr int EPC = DT<T>::EPC;
-    const int c1 = C1 / EPC, c2 = C2 / EPC, ct = c1 + c2;
+    const int c1 = C1 / EPC, c2 = C2 / EPC;
+    const int c0 = a ? 0 : c1, ct = c1 + c2 - c0;     // chunk columns written per row
     const long n = rows * ct;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const long r = i / ct;
-        const int c = (int)(i - r * ct);
+        const int c = c0 + (int)(i - r * ct);
         const u32x4 v = (c < c1) ? *reinterpret_cast<const u32x4*>(a + r * C1 + c * EPC)
                                  : *reinterpret_cast<const u32x4*>(b + r * C2 + (c - c1) * EPC);
         *reinterpret_cast<u32x4*>(out + r * (C1 + C2) + c * EPC) = v;

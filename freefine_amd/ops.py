@@ -164,7 +164,7 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
     else:
         if out is None:
             out = torch.empty(*x.shape[:-1], n_out, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
-        d.ldo = n_out
+        d.ldo = out.stride(-2) if out.ndim > 1 else n_out          # a column view of a wider buffer (cat_dst) keeps the buffer's row stride
     d.ldr = residual.shape[-1] if residual is not None else 0
     d.out = out.data_ptr()
     d.flags, d.alpha, d.conv = flags, alpha, 0
@@ -196,7 +196,7 @@ def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, ou
     d.ldrb = (rowbias_ld or rowbias.stride(0)) if rowbias is not None else 0
     if out is None:
         out = torch.empty(B, Hout * Wout, N, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
-    d.out, d.ldo = out.data_ptr(), N
+    d.out, d.ldo = out.data_ptr(), out.stride(-2)                   # (a column view of a wider buffer keeps the buffer's row stride)
     d.ldr = residual.shape[-1] if residual is not None else 0
     d.Hin, d.Win, d.Cin, d.Hout, d.Wout = Hin, Win, Cin, Hout, Wout
     d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
@@ -398,13 +398,30 @@ def nhwc_to_nchw_f32(src, C_, H, W, out=None):
 
 
 def concat(a, b, out=None):
+    """[a | b] along the channel axis.  If `a` is the left column view of a cat_dst() buffer (its producer already wrote it in place),
+    only b is copied and that buffer is returned."""
     lib = L.load()
     C1, C2 = a.shape[-1], b.shape[-1]
     rows = a.numel() // C1
+    base = getattr(a, "_ffn_cat_base", None)
+    if out is None and base is not None and base.shape[-1] == C1 + C2:
+        L.check(lib.ffn_concat(_stream(), _dt(b), None, b.data_ptr(), base.data_ptr(), rows, C1, C2), "ffn_concat")
+        return base
+    if base is not None:
+        a = a.contiguous()
     if out is None:
         out = torch.empty(*a.shape[:-1], C1 + C2, dtype=a.dtype, device=a.device)
     L.check(lib.ffn_concat(_stream(), _dt(a), a.data_ptr(), b.data_ptr(), out.data_ptr(), rows, C1, C2), "ffn_concat")
     return out
+
+
+def cat_dst(shape_lead, C1, C2, dtype, device):
+    """Destination for a producer whose output will be concatenated with C2 more channels: a [*, C1 + C2] buffer and its left
+    [*, C1] column view (pass the view as `out=` to linear / conv3x3; concat(view, skip) then only copies the skip)."""
+    base = torch.empty(*shape_lead, C1 + C2, dtype=dtype, device=device)
+    view = base[..., :C1]
+    view._ffn_cat_base = base
+    return view
 
 
 def timestep_freqs(dim, device, max_period=10000.0, shift=0.0):

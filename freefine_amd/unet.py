@@ -355,7 +355,7 @@ class HipUNet:
         B, HW, C = x.shape
         return ops.groupnorm(x, gb[0], gb[1], self.cfg.norm_num_groups, eps, silu=silu)
 
-    def _resblock(self, r, x, B, H, W, temb_all):
+    def _resblock(self, r, x, B, H, W, temb_all, out=None):
         cin = x.shape[-1]
         h = self._gn(x, r.n1, self.cfg.norm_eps, True)
         rb = temb_all[:, r.temb_off:r.temb_off + r.cout]
@@ -363,7 +363,7 @@ class HipUNet:
         h = self._gn(h, r.n2, self.cfg.norm_eps, True)
         if r.sc is not None:
             x = ops.linear(x, r.sc[0], r.sc[1], K=cin)
-        return ops.conv3x3(h, r.c2[0], r.c2[1], B, H, W, r.cout, residual=x)
+        return ops.conv3x3(h, r.c2[0], r.c2[1], B, H, W, r.cout, residual=x, out=out)
 
     def _attention(self, t, is_cross, place, q, k, vt, ldq_view, B, S, Sk):
         D = t.C // t.heads
@@ -379,7 +379,7 @@ class HipUNet:
             return ops.attention(q, k2, vt2, t.heads, scale, plan["passes"], Sk=2 * Sk, C=t.C)
         return ops.attention(q, k, vt, t.heads, scale, plan["passes"], Sk=Sk, C=t.C, w_dev=self.cg_dev if plan["needs_cg"] else None)
 
-    def _transformer_block(self, t, x, B, H, W, place, kv_text):
+    def _transformer_block(self, t, x, B, H, W, place, kv_text, out=None):
         S, C = H * W, t.C
         res0 = x
         h = self._gn(x, t.norm, 1e-6, False)
@@ -400,7 +400,7 @@ class HipUNet:
         y = ops.layernorm(h, *t.ln[2])
         y = ops.linear(y, t.ff1[0], t.ff1[1], K=C, geglu=True)
         h = ops.linear(y, t.ff2[0], t.ff2[1], K=4 * C, residual=h)
-        return ops.linear(h, t.proj_out[0], t.proj_out[1], K=C, residual=res0)
+        return ops.linear(h, t.proj_out[0], t.proj_out[1], K=C, residual=res0, out=out)
 
     def _run(self, sample, text_kv):
         cfg = self.cfg
@@ -429,18 +429,23 @@ class HipUNet:
                 skips.append((x, H, W))
         x = self._resblock(self.mid.res[0], x, B, H, W, temb_all)
         x = self._transformer_block(self.mid.attn[0], x, B, H, W, "mid", next(ti))
-        x = self._resblock(self.mid.res[1], x, B, H, W, temb_all)
+        # Up path: whatever produces the input of a skip concatenation writes it straight into the left columns of the concatenated
+        # buffer (ldo = C1 + C2), so the concat only copies the skip tensor
+        def cat_dst(C1, HW):
+            return ops.cat_dst((B, HW), C1, skips[-1][0].shape[-1], dt, x.device) if skips else None
+        x = self._resblock(self.mid.res[1], x, B, H, W, temb_all, out=cat_dst(self.mid.res[1].cout, H * W))
         for i, blk in enumerate(self.up):
             for j, r in enumerate(blk.res):
                 s, sh, sw = skips.pop()
                 assert (sh, sw) == (H, W)
                 x = ops.concat(x, s)
-                x = self._resblock(r, x, B, H, W, temb_all)
+                dst = cat_dst(r.cout, H * W) if j + 1 < len(blk.res) else None      # the next resblock of this block concatenates again
+                x = self._resblock(r, x, B, H, W, temb_all, out=None if blk.attn else dst)
                 if blk.attn:
-                    x = self._transformer_block(blk.attn[j], x, B, H, W, "up", next(ti))
+                    x = self._transformer_block(blk.attn[j], x, B, H, W, "up", next(ti), out=dst)
             if blk.up is not None:
                 C = x.shape[-1]
-                x = ops.conv3x3(x, blk.up[0], blk.up[1], B, H, W, C, upsample=True)
+                x = ops.conv3x3(x, blk.up[0], blk.up[1], B, H, W, C, upsample=True, out=cat_dst(C, 4 * H * W))
                 H, W = 2 * H, 2 * W
         x = self._gn(x, self.norm_out, cfg.norm_eps, True)
         eps = ops.conv3x3(x, self.conv_out[0], self.conv_out[1], B, H, W, x.shape[-1], out_f32=True)

@@ -181,6 +181,8 @@ typedef struct ffn_pack_desc {
 } ffn_pack_desc;
 int ffn_pack_nchw(void* stream, int dtype, const ffn_pack_desc* d);
 int ffn_nhwc_to_nchw_f32(void* stream, const float* src, float* dst, int B, int HW, int C, int ld);
+/* out[r][0:C1] = a[r], out[r][C1:C1+C2] = b[r].  a == NULL: the left block is already in place (its producer wrote it with
+ * ldo = C1 + C2), only b is copied */
 int ffn_concat(void* stream, int dtype, const void* a, const void* b, void* out, long rows, int C1, int C2);
 int ffn_timestep_embed(void* stream, int dtype, const float* t_dev, const float* freq, void* out, int B, int half, int flip);
 int ffn_transpose(void* stream, int dtype, const void* src, void* dst, int B, int R, int C, int ld_src, int ld_dst);
