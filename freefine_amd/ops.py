@@ -159,7 +159,10 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
         flags |= L.IG_OUT_TRANSPOSED
         nb = M // d.rows_per_batch
         if out is None:
-            out = torch.zeros(nb, N, transposed_ld, dtype=x.dtype, device=x.device)
+            # columns past the rows of a batch are padding the attention kernels may multiply by P = 0: they must be finite, so a
+            # padded buffer is zero-filled; without padding (every UNet level: S % 8 == 0) the GEMM writes every element
+            alloc = torch.zeros if transposed_ld > d.rows_per_batch else torch.empty
+            out = alloc(nb, N, transposed_ld, dtype=x.dtype, device=x.device)
         d.ldo = transposed_ld
     else:
         if out is None:
