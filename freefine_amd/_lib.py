@@ -77,6 +77,9 @@ SYMBOLS = {
     "ffn_igemm_tune_entry_ints": (_i, []),
     "ffn_igemm_tune_export": (_i, [C.POINTER(C.c_int), _i]),
     "ffn_igemm_tune_import": (_i, [C.POINTER(C.c_int), _i]),
+    "ffn_igemm_tune_stamp": (_i, []),
+    "ffn_igemm_tune_clear": (_i, []),
+    "ffn_igemm_tune_enable": (_i, [_i]),
     "ffn_igemm_num_configs": (_i, []),
     "ffn_igemm_force_config": (_i, [_i]),
     "ffn_igemm_variant": (_i, [C.POINTER(IgemmDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

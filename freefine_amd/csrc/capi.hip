@@ -250,6 +250,7 @@ static const IgCfgInfo kCfg[CFG_COUNT] = {{64, 64, 2, 2}, {128, 64, 4, 2}, {128,
                                           {128, 320, 4, 4}, {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 128, 4, 4},    // halo kernel (3x3 stride-1 convs)
                                           {256, 320, 2, 4}, {256, 256, 2, 4}, {192, 320, 2, 4}, {192, 256, 2, 4}};     // ping-pong kernel (igemm_p8.h)
 struct IgChoice { int cfg, splitk; };
+struct TunedEntry { IgChoice ch; bool validated; };   // imported entries (file / another rank) are checked against the problem at first use
 
 static bool is_halo_cfg(int cfg) { return cfg == CFG_H_128x320 || cfg == CFG_H_256x128 || cfg == CFG_H_256x256 || cfg == CFG_H_128x128; }
 static bool is_pp_cfg(int cfg) { return cfg >= CFG_PP_256x320 && cfg <= CFG_PP_192x256; }
@@ -414,7 +415,7 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
 }
 
 struct TuneKey {
-    int M, N, K, conv, Cin, Hin, Win, stride, upsample, flags, lda, splitk, ptrs, wslabs, rpb, alpha1, ldo;
+    int M, N, K, conv, Cin, Hin, Win, stride, upsample, flags, lda, splitk, ptrs, wslabs, rpb, alpha1, ldo, pad, Hout, Wout, Kpad, ldr, dtype;
     bool operator==(const TuneKey& o) const { return memcmp(this, &o, sizeof(TuneKey)) == 0; }
 };
 struct TuneKeyHash {
@@ -429,23 +430,44 @@ static TuneKey tune_key(const ffn_igemm_desc& d) {
     TuneKey k;
     memset(&k, 0, sizeof(k));
     k.M = d.M; k.N = d.N; k.K = d.K; k.conv = d.conv; k.flags = d.flags; k.lda = d.lda; k.splitk = d.splitk;
-    if (d.conv) { k.Cin = d.Cin; k.Hin = d.Hin; k.Win = d.Win; k.stride = d.stride; k.upsample = d.upsample; }
+    if (d.conv) { k.Cin = d.Cin; k.Hin = d.Hin; k.Win = d.Win; k.stride = d.stride; k.upsample = d.upsample; k.pad = d.pad; k.Hout = d.Hout; k.Wout = d.Wout; }
+    k.Kpad = d.Kpad;
+    k.ldr = d.residual ? d.ldr : 0;
     k.ptrs = (d.bias ? 1 : 0) | (d.rowbias ? 2 : 0) | (d.residual ? 4 : 0) | (d.ws && d.ws_bytes > 0 ? 8 : 0);
     const long per = (long)d.M * d.N * 4;
-    k.wslabs = d.ws ? (int)(d.ws_bytes / per > 64 ? 64 : d.ws_bytes / per) : 0;      // how many split-K slabs the workspace holds
+    k.wslabs = d.ws ? (int)(d.ws_bytes / per > 1024 ? 1024 : d.ws_bytes / per) : 0;      // how many split-K slabs the workspace holds
     k.rpb = d.rows_per_batch;
     k.alpha1 = d.alpha == 1.0f;
     k.ldo = d.ldo;
     return k;
 }
 static std::mutex g_tune_mu;
-static std::unordered_map<TuneKey, IgChoice, TuneKeyHash> g_tuned;
+static std::unordered_map<TuneKey, TunedEntry, TuneKeyHash> g_tuned;
+static int g_tune_runtime = 1;      // ffn_igemm_tune_enable(0): no more timing-based tuning in this process (after a table sync)
 static bool tune_enabled() {
     static const bool on = [] { const char* e = getenv("FFN_IGEMM_TUNE"); return !(e && atoi(e) == 0); }();
-    return on;
+    return on && g_tune_runtime;
 }
 // the deterministic rule-based choice (also what f32 parity mode uses): igemm_plan_for + igemm_exec_cfg mapped to a configuration
 static IgChoice heuristic_choice(const ffn_igemm_desc& d) {
+    // the ping-pong tile first, where its unsplit form applies and its tiles fill at least 3/4 of the chip: tile height = the one whose
+    // tile count wastes the least of the last round of workgroups (the rule pp_trans_tile uses).  Without this, every launch that
+    // cannot be tuned (FFN_IGEMM_TUNE=0, stream capture before a shape was seen, out aliasing residual) fell back to the 2-stage kernels
+    if (d.splitk <= 1) {
+        for (int bn : {320, 256}) {
+            if (d.N % bn != 0) continue;
+            long best = -1;
+            int bh = 0;
+            for (int h : {256, 192}) {
+                if (!pp_ok(d, h, bn)) continue;
+                const long tiles = (long)((d.M + h - 1) / h) * (d.N / bn);
+                if (tiles * 4 < (long)device_cus() * 3) continue;
+                const long cost = ((tiles + device_cus() - 1) / device_cus()) * h;
+                if (best < 0 || cost < best) { best = cost; bh = h; }
+            }
+            if (best >= 0) return IgChoice{bn == 320 ? (bh == 256 ? CFG_PP_256x320 : CFG_PP_192x320) : (bh == 256 ? CFG_PP_256x256 : CFG_PP_192x256), 1};
+        }
+    }
     int bm, bn, sk, ns, nw;
     igemm_plan_for(FFN_BF16, d, &bm, &bn, &sk);
     igemm_exec_cfg(FFN_BF16, d, bm, bn, sk, &ns, &nw);
@@ -537,7 +559,20 @@ static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
     {
         std::lock_guard<std::mutex> lk(g_tune_mu);
         auto it = g_tuned.find(key);
-        if (it != g_tuned.end()) return launch_bf16_cfg<AMODE>(s, d, it->second);
+        if (it != g_tuned.end()) {
+            if (!it->second.validated) {
+                // an entry that came in as data (a tune file, another rank's table): launch it only if this build would have
+                // offered exactly that (configuration, K split) for THIS problem -- workspace capacity, split legality, tile
+                // applicability are all decided in candidates_for; anything else is dropped and the problem is tuned afresh
+                IgChoice cand[40];
+                const int nc = candidates_for(d, cand, 40);
+                bool ok = false;
+                for (int i = 0; i < nc; ++i) ok |= cand[i].cfg == it->second.ch.cfg && cand[i].splitk == it->second.ch.splitk;
+                if (ok) it->second.validated = true;
+                else g_tuned.erase(it), it = g_tuned.end();
+            }
+            if (it != g_tuned.end()) return launch_bf16_cfg<AMODE>(s, d, it->second.ch);
+        }
     }
     if (!tune_enabled() || cap != hipStreamCaptureStatusNone || aliased) return launch_bf16_cfg<AMODE>(s, d, heuristic_choice(d));
     std::lock_guard<std::mutex> lk(g_tune_mu);       // one tuning at a time
@@ -566,7 +601,7 @@ static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    g_tuned[key] = best;
+    g_tuned[key] = TunedEntry{best, true};
     static const bool verbose = getenv("FFN_IGEMM_TUNE_VERBOSE") != nullptr;
     if (verbose)
         fprintf(stderr, "[ffn tune] %s M=%d N=%d K=%d flags=%d -> %dx%d split %d (%.1f us, %d candidates)\n", d.conv ? "conv" : "dense", d.M, d.N,
@@ -575,17 +610,34 @@ static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
 }
 // ---- the tuned table as data: export / import (persist it across processes, broadcast rank 0's table so that every rank of a
 // sharded run launches the same configurations -- bf16 results then are bit-identical across ranks)
-static constexpr int kTuneEntryInts = (int)(sizeof(TuneKey) / sizeof(int)) + 2;
+// entry = [stamp | TuneKey | cfg | splitk]; the stamp names the layout of this build's table (key size, configuration list, arch):
+// entries written by a different build are ignored on import
+static constexpr int kTuneEntryInts = (int)(sizeof(TuneKey) / sizeof(int)) + 3;
+static constexpr int kTuneStamp = 0x67780000 ^ (950 << 4) ^ ((int)sizeof(TuneKey) << 8) ^ CFG_COUNT ^ (3 << 24);      // gfx950, table layout 3
 extern "C" int ffn_igemm_tune_entry_ints(void) { return kTuneEntryInts; }
+extern "C" int ffn_igemm_tune_stamp(void) { return kTuneStamp; }
+extern "C" int ffn_igemm_tune_clear(void) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    const int n = (int)g_tuned.size();
+    g_tuned.clear();
+    return n;
+}
+extern "C" int ffn_igemm_tune_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    const int prev = g_tune_runtime;
+    g_tune_runtime = on ? 1 : 0;
+    return prev;
+}
 extern "C" int ffn_igemm_tune_export(int* buf, int max_entries) {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     int n = 0;
     for (const auto& kv : g_tuned) {
         if (buf && n < max_entries) {
             int* e = buf + (long)n * kTuneEntryInts;
-            memcpy(e, &kv.first, sizeof(TuneKey));
-            e[kTuneEntryInts - 2] = kv.second.cfg;
-            e[kTuneEntryInts - 1] = kv.second.splitk;
+            e[0] = kTuneStamp;
+            memcpy(e + 1, &kv.first, sizeof(TuneKey));
+            e[kTuneEntryInts - 2] = kv.second.ch.cfg;
+            e[kTuneEntryInts - 1] = kv.second.ch.splitk;
         }
         ++n;
     }
@@ -597,11 +649,12 @@ extern "C" int ffn_igemm_tune_import(const int* buf, int n_entries) {
     int n = 0;
     for (int i = 0; i < n_entries; ++i) {
         const int* e = buf + (long)i * kTuneEntryInts;
+        if (e[0] != kTuneStamp) continue;                                       // a table from another build / layout / arch
         TuneKey k;
-        memcpy(&k, e, sizeof(TuneKey));
+        memcpy(&k, e + 1, sizeof(TuneKey));
         const IgChoice ch{e[kTuneEntryInts - 2], e[kTuneEntryInts - 1]};
-        if (ch.cfg < 0 || ch.cfg >= CFG_COUNT || ch.splitk < 1) continue;       // a table from another build: ignore what does not fit
-        g_tuned[k] = ch;
+        if (ch.cfg < 0 || ch.cfg >= CFG_COUNT || ch.splitk < 1) continue;
+        g_tuned[k] = TunedEntry{ch, false};      // validated against the actual problem (candidates_for) at its first lookup
         ++n;
     }
     return n;
@@ -610,7 +663,7 @@ static bool tuned_lookup(const ffn_igemm_desc& d, IgChoice* ch) {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = g_tuned.find(tune_key(d));
     if (it == g_tuned.end()) return false;
-    *ch = it->second;
+    *ch = it->second.ch;
     return true;
 }
 

@@ -27,30 +27,46 @@ def shard_indices(n, rank, world):
     return idx[rank:total:world]
 
 
-def broadcast_state(state, shapes, device, src=0, chunk_elems=256 * 1024 * 1024):
-    """state: dict name -> fp32 tensor on rank `src` (None elsewhere); shapes: the same name -> shape table on every rank."""
-    names = list(shapes)
-    sizes = [int(torch.tensor(shapes[n]).prod()) for n in names]
-    out = {}
+def broadcast_state(state, shapes, device, src=0, chunk_elems=256 * 1024 * 1024, matrix_dtype=torch.float32):
+    """state: dict name -> tensor on rank `src` (None elsewhere); shapes: the same name -> shape table on every rank.
+    Returns name -> tensor ON `device` for every rank (views into a few large flat receive buffers: no host bounce -- the packers of
+    HipUNet / HipVAE read them where they landed).  `matrix_dtype=torch.bfloat16` halves the payload of the >= 2-D tensors (Linear /
+    conv weights) for the bf16 fast mode: the packers round those to bf16 anyway (RNE, idempotent), so the packed weights are
+    bit-identical to rank `src`'s; 1-D tensors (biases, norm scales: kept fp32 by every kernel) always travel in fp32.
+    Rank `src` gets the views of its own send buffers, so every rank builds its engine from the same bits."""
     rank = dist.get_rank()
-    i = 0
-    while i < len(names):
-        j, tot = i, 0
-        while j < len(names) and (tot == 0 or tot + sizes[j] <= chunk_elems):
-            tot += sizes[j]
-            j += 1
-        if rank == src:
-            flat = torch.cat([state[n].reshape(-1).float() for n in names[i:j]]).to(device)
-        else:
-            flat = torch.empty(tot, dtype=torch.float32, device=device)
-        dist.broadcast(flat, src=src)
-        off = 0
-        flat_cpu = flat.cpu()
-        for n, s in zip(names[i:j], sizes[i:j]):
-            out[n] = flat_cpu[off:off + s].reshape(shapes[n]).clone()
-            off += s
-        i = j
+    out = {}
+    groups = [([n for n in shapes if len(shapes[n]) >= 2], matrix_dtype), ([n for n in shapes if len(shapes[n]) < 2], torch.float32)]
+    for names, dt in groups:
+        sizes = [int(math.prod(shapes[n])) for n in names]
+        i = 0
+        while i < len(names):
+            j, tot = i, 0
+            while j < len(names) and (tot == 0 or tot + sizes[j] <= chunk_elems):
+                tot += sizes[j]
+                j += 1
+            if rank == src:
+                flat = torch.cat([state[n].reshape(-1).to(dt) for n in names[i:j]]).to(device)
+            else:
+                flat = torch.empty(tot, dtype=dt, device=device)
+            dist.broadcast(flat, src=src)
+            off = 0
+            for n, sz in zip(names[i:j], sizes[i:j]):
+                out[n] = flat[off:off + sz].view(shapes[n])
+                off += sz
+            i = j
     return out
+
+
+def broadcast_object(obj, src=0):
+    """small host objects (config dicts) from rank `src` to everyone"""
+    box = [obj if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def active():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 def gather_results(local_results):
@@ -70,13 +86,22 @@ def gather_results(local_results):
     return merged
 
 
-def sync_tune_table(src=0):
-    """every rank adopts rank `src`'s igemm tuning table (freefine_amd.ops.tune_table_*): identical tile / split-K choices on all
-    ranks, hence bit-identical bf16 results across the ranks of a sharded run (the tuner picks by timing, which may differ per GPU).
-    Works on any backend: the table is a small int32 tensor shipped with broadcast_object_list."""
+def sync_tune_table(src=0, freeze=True):
+    """every rank REPLACES its igemm tuning table by rank `src`'s (freefine_amd.ops.tune_table_*) and, with `freeze`, stops
+    timing-based tuning on every rank: shapes in the table launch rank `src`'s choice, shapes first seen later take the deterministic
+    rule -- identical tile / split-K choices on all ranks either way, hence bit-identical bf16 results across the ranks of a sharded
+    run (the tuner picks by timing, which may differ per GPU).  Works on any backend: the table is a small int32 tensor shipped
+    with broadcast_object_list."""
     from . import ops
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
     box = [ops.tune_table_export() if dist.get_rank() == src else None]
     dist.broadcast_object_list(box, src=src)
-    return ops.tune_table_import(box[0]) if dist.get_rank() != src else box[0].shape[0]
+    if dist.get_rank() != src:
+        ops.tune_table_clear()
+        n = ops.tune_table_import(box[0])
+    else:
+        n = box[0].shape[0]
+    if freeze:
+        ops.tune_enable(False)
+    return n

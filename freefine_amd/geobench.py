@@ -98,6 +98,45 @@ def _prefetch(cases, dst_base, depth, dsize, loader=None):
         yield item
 
 
+def warm_and_sync(model, batch, params, dsize=(512, 512), variant="2d", src=0):
+    """Multi-rank runs in bf16 fast mode: every rank edits one SYNTHETIC batch of the run's shape eagerly (this tunes every igemm
+    shape of the schedule on its own GPU), then adopts rank `src`'s tuning table and stops tuning (dist.sync_tune_table) BEFORE any
+    forward graph is captured -- every rank then launches identical tile / split-K configurations, so a case's bf16 result does not
+    depend on the rank that edited it.  A collective: every rank calls it (run() does, also on ranks that own no case)."""
+    import torch
+    from . import dist as FD
+    if not FD.active():
+        return 0
+    unet = getattr(model, "unet", None)
+    if unet is not None and getattr(unet, "dtype", None) == torch.bfloat16:      # f32 parity mode never tunes: nothing to align
+        H, W = dsize[1], dsize[0]
+        rng = np.random.default_rng(12345)
+        cases = []
+        for j in range(batch):
+            m0 = np.zeros((H, W), np.uint8)
+            m0[H // 3:H // 2, W // 5:2 * W // 5] = 1
+            m1 = np.roll(m0, W // 8, axis=1)
+            c = dict(ori_img=rng.integers(0, 256, (H, W, 3), dtype=np.uint8), coarse_input=rng.integers(0, 256, (H, W, 3), dtype=np.uint8),
+                     ori_mask=m0, target_mask=m1 * 255, guidance_text="" if variant == "2d" else "object", draw_mask=None)
+            if variant == "2d":
+                c.update(use_auto_draw=True, reduce_inp_artifacts=True, cons_area=np.maximum(m0, m1))
+            else:
+                c.update(draw_mask=np.maximum(m0, m1), reduce_inp_artifacts=True, cons_area=np.maximum(m0, m1))
+            cases.append(c)
+        was = model.unet.use_graph
+        model.unet.use_graph = False
+        kw = dict(end_step=params["end_step"], num_step=params["num_step"], start_step=params["start_step"], end_scale=params["end_scale"], verbose=False)
+        if batch > 1:
+            model.FreeFine_generation_batch(cases, params["guidance_scale"], params["eta"], seeds=0, **kw)
+        else:
+            c = dict(cases[0])
+            model.FreeFine_generation(c.pop("ori_img"), c.pop("ori_mask"), c.pop("coarse_input"), c.pop("target_mask"), c.pop("guidance_text"),
+                                      params["guidance_scale"], params["eta"], seed=0, **kw, **c)
+        model.unet.use_graph = was
+        torch.cuda.synchronize()
+    return FD.sync_tune_table(src)
+
+
 def run(model, dst_base, batch=4, params=None, rank=0, world=1, check_exist=True, verbose=True, dsize=(512, 512), variant="2d"):
     """edit every case of the variant's annotation file that this rank owns; rank 0 writes the variant's result JSON
     (2d: annotations_2d.json -> generated_results_freefine_2d.json; 3d_depth: annotations.json -> generated_results_freefine_depth.json).
@@ -115,6 +154,8 @@ def run(model, dst_base, batch=4, params=None, rank=0, world=1, check_exist=True
     mine = [cl[i] for i in FD.shard_indices(len(cl), rank, world)]
     results = []
     pending = []
+    if world > 1:
+        warm_and_sync(model, batch, params, dsize, variant)
 
     def flush():
         if not pending:

@@ -306,8 +306,13 @@ def groupnorm(x, gamma, beta, G, eps, silu=False, out=None, ws=None):
         partial = scale = shift = None
     else:
         partial, scale, shift = ws if ws is not None else gn_workspace(B, HW, Cc, x.device)
-    L.check(lib.ffn_groupnorm(_stream(), _dt(x), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B, HW, Cc, G, eps,
-                              1 if silu else 0, _p(partial), _p(scale), _p(shift)), "ffn_groupnorm")
+    call = lambda: lib.ffn_groupnorm(_stream(), _dt(x), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B, HW, Cc, G, eps,
+                                     1 if silu else 0, _p(partial), _p(scale), _p(shift))
+    if _PROF is None:
+        L.check(call(), "ffn_groupnorm")
+    else:       # algorithmic bytes: one read + one write (the three-launch form reads x twice: that shows as a lower GB/s)
+        name = f"gn_fused_kernel<{_tname(x)}>" if partial is None else f"gn_partial+gn_finalize+gn_apply<{_tname(x)}>"
+        L.check(_timed(name, 0.0, 2.0 * x.numel() * x.element_size(), call), "ffn_groupnorm")
     return out
 
 
@@ -317,8 +322,11 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
     M = x.numel() // Cc
     if out is None:
         out = torch.empty_like(x)
-    L.check(lib.ffn_layernorm(_stream(), _dt(x), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, Cc, eps),
-            "ffn_layernorm")
+    call = lambda: lib.ffn_layernorm(_stream(), _dt(x), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, Cc, eps)
+    if _PROF is None:
+        L.check(call(), "ffn_layernorm")
+    else:
+        L.check(_timed(f"layernorm_kernel<{_tname(x)}>", 0.0, 2.0 * x.numel() * x.element_size(), call), "ffn_layernorm")
     return out
 
 
@@ -328,7 +336,8 @@ def softmax_rows(x, scale=1.0, out=None):
     M = x.numel() // N
     if out is None:
         out = torch.empty_like(x)
-    L.check(lib.ffn_softmax_rows(_stream(), _dt(x), x.data_ptr(), out.data_ptr(), M, N, scale), "ffn_softmax_rows")
+    L.check(_timed(f"softmax_rows_kernel<{_tname(x)}>", 0.0, 2.0 * x.numel() * x.element_size(),
+                   lambda: lib.ffn_softmax_rows(_stream(), _dt(x), x.data_ptr(), out.data_ptr(), M, N, scale)), "ffn_softmax_rows")
     return out
 
 
@@ -340,8 +349,9 @@ def cfg_masked(eps_u, eps_c, mask_f, cfg, out=None):
     if out is None:
         out = torch.empty_like(eps_u)
     HW = eps_u.shape[-1] * eps_u.shape[-2]
-    L.check(lib.ffn_cfg_masked(_stream(), eps_u.data_ptr(), eps_c.data_ptr(), _p(mask_f), float(cfg), out.data_ptr(),
-                               eps_u.numel(), HW), "ffn_cfg_masked")
+    L.check(_timed("cfg_masked_kernel", 0.0, 12.0 * eps_u.numel(),
+                   lambda: lib.ffn_cfg_masked(_stream(), eps_u.data_ptr(), eps_c.data_ptr(), _p(mask_f), float(cfg), out.data_ptr(),
+                                              eps_u.numel(), HW)), "ffn_cfg_masked")
     return out
 
 
@@ -349,8 +359,9 @@ def ddim_inv_step(eps, x, c_bt, c_at, c_an, c_bn, want_pred_x0=False):
     lib = L.load()
     x_next = torch.empty_like(x)
     p0 = torch.empty_like(x) if want_pred_x0 else None
-    L.check(lib.ffn_ddim_inv_step(_stream(), eps.data_ptr(), x.data_ptr(), c_bt, c_at, c_an, c_bn, x_next.data_ptr(), _p(p0),
-                                  x.numel()), "ffn_ddim_inv_step")
+    L.check(_timed("ddim_inv_step_kernel", 0.0, (12.0 + (4.0 if want_pred_x0 else 0.0)) * x.numel(),
+                   lambda: lib.ffn_ddim_inv_step(_stream(), eps.data_ptr(), x.data_ptr(), c_bt, c_at, c_an, c_bn, x_next.data_ptr(), _p(p0),
+                                                 x.numel())), "ffn_ddim_inv_step")
     return x_next, p0
 
 
@@ -366,7 +377,7 @@ def ddim_ctrl_step(eps, x, noise, m_f, om_f, c_bt, c_at, c_ap, c_dir, c_dirm, st
     for b in range(rows):
         d.c_dirm[b], d.stdv[b], d.row_masked[b] = c_dirm[b], stdv[b], int(row_masked[b])
     d.rows, d.CHW, d.HW = rows, x[0].numel(), x.shape[-1] * x.shape[-2]
-    L.check(lib.ffn_ddim_ctrl_step(_stream(), CT.byref(d)), "ffn_ddim_ctrl_step")
+    L.check(_timed("ddim_ctrl_step_kernel", 0.0, 20.0 * x.numel(), lambda: lib.ffn_ddim_ctrl_step(_stream(), CT.byref(d))), "ffn_ddim_ctrl_step")
     return x_prev, p0
 
 
@@ -387,7 +398,8 @@ def pack_nchw(src, src_rows, CP, dtype, out=None):
         for i in range(nb):
             d.src_row[i] = src_rows[b0 + i]
         d.B, d.Cl, d.CP, d.HW = nb, Cl, CP, H * W
-        L.check(lib.ffn_pack_nchw(_stream(), _dt(out), CT.byref(d)), "ffn_pack_nchw")
+        L.check(_timed(f"pack_nchw_kernel<{_tname(out)}>", 0.0, nb * H * W * (4.0 * Cl + CP * out.element_size()),
+                       lambda: lib.ffn_pack_nchw(_stream(), _dt(out), CT.byref(d))), "ffn_pack_nchw")
     return out
 
 
@@ -396,7 +408,8 @@ def nhwc_to_nchw_f32(src, C_, H, W, out=None):
     B, HW, ld = src.shape
     if out is None:
         out = torch.empty(B, C_, H, W, dtype=torch.float32, device=src.device)
-    L.check(lib.ffn_nhwc_to_nchw_f32(_stream(), src.data_ptr(), out.data_ptr(), B, HW, C_, ld), "ffn_nhwc_to_nchw_f32")
+    L.check(_timed("nhwc_to_nchw_f32_kernel", 0.0, 8.0 * B * HW * C_,
+                   lambda: lib.ffn_nhwc_to_nchw_f32(_stream(), src.data_ptr(), out.data_ptr(), B, HW, C_, ld)), "ffn_nhwc_to_nchw_f32")
     return out
 
 
@@ -408,13 +421,15 @@ def concat(a, b, out=None):
     rows = a.numel() // C1
     base = getattr(a, "_ffn_cat_base", None)
     if out is None and base is not None and base.shape[-1] == C1 + C2:
-        L.check(lib.ffn_concat(_stream(), _dt(b), None, b.data_ptr(), base.data_ptr(), rows, C1, C2), "ffn_concat")
+        L.check(_timed(f"concat_kernel<{_tname(b)}>", 0.0, 2.0 * rows * C2 * b.element_size(),
+                       lambda: lib.ffn_concat(_stream(), _dt(b), None, b.data_ptr(), base.data_ptr(), rows, C1, C2)), "ffn_concat")
         return base
     if base is not None:
         a = a.contiguous()
     if out is None:
         out = torch.empty(*a.shape[:-1], C1 + C2, dtype=a.dtype, device=a.device)
-    L.check(lib.ffn_concat(_stream(), _dt(a), a.data_ptr(), b.data_ptr(), out.data_ptr(), rows, C1, C2), "ffn_concat")
+    L.check(_timed(f"concat_kernel<{_tname(a)}>", 0.0, 2.0 * rows * (C1 + C2) * a.element_size(),
+                   lambda: lib.ffn_concat(_stream(), _dt(a), a.data_ptr(), b.data_ptr(), out.data_ptr(), rows, C1, C2)), "ffn_concat")
     return out
 
 
@@ -438,8 +453,9 @@ def timestep_embed(t_dev, freq, B, dtype, flip=True, out=None):
     half = freq.numel()
     if out is None:
         out = torch.empty(B, 2 * half, dtype=dtype, device=freq.device)
-    L.check(lib.ffn_timestep_embed(_stream(), _dt(out), t_dev.data_ptr(), freq.data_ptr(), out.data_ptr(), B, half,
-                                   1 if flip else 0), "ffn_timestep_embed")
+    L.check(_timed(f"timestep_embed_kernel<{_tname(out)}>", 0.0, float(out.numel() * out.element_size()),
+                   lambda: lib.ffn_timestep_embed(_stream(), _dt(out), t_dev.data_ptr(), freq.data_ptr(), out.data_ptr(), B, half,
+                                                  1 if flip else 0)), "ffn_timestep_embed")
     return out
 
 
@@ -450,7 +466,8 @@ def transpose(src, ld_dst=None, out=None):
     ld_dst = ld_dst or R
     if out is None:
         out = torch.zeros(B, Cc, ld_dst, dtype=src.dtype, device=src.device)
-    L.check(lib.ffn_transpose(_stream(), _dt(src), src.data_ptr(), out.data_ptr(), B, R, Cc, Cc, ld_dst), "ffn_transpose")
+    L.check(_timed(f"transpose_kernel<{_tname(src)}>", 0.0, 2.0 * src.numel() * src.element_size(),
+                   lambda: lib.ffn_transpose(_stream(), _dt(src), src.data_ptr(), out.data_ptr(), B, R, Cc, Cc, ld_dst)), "ffn_transpose")
     return out
 
 
@@ -458,7 +475,8 @@ def cast(src, dtype, out=None):
     lib = L.load()
     if out is None:
         out = torch.empty(src.shape, dtype=dtype, device=src.device)
-    L.check(lib.ffn_cast(_stream(), _dt(src), _dt(out), src.data_ptr(), out.data_ptr(), src.numel()), "ffn_cast")
+    L.check(_timed(f"cast_kernel<{_tname(src)}, {_tname(out)}>", 0.0, float(src.numel() * (src.element_size() + out.element_size())),
+                   lambda: lib.ffn_cast(_stream(), _dt(src), _dt(out), src.data_ptr(), out.data_ptr(), src.numel())), "ffn_cast")
     return out
 
 
@@ -468,7 +486,8 @@ def image_to_nhwc(img_u8, CP, dtype, out=None):
     B, H, W, _ = img_u8.shape
     if out is None:
         out = torch.empty(B, H * W, CP, dtype=dtype, device=img_u8.device)
-    L.check(lib.ffn_image_to_nhwc(_stream(), _dt(out), img_u8.data_ptr(), out.data_ptr(), B * H * W, CP), "ffn_image_to_nhwc")
+    L.check(_timed(f"image_to_nhwc_kernel<{_tname(out)}>", 0.0, B * H * W * (3.0 + CP * out.element_size()),
+                   lambda: lib.ffn_image_to_nhwc(_stream(), _dt(out), img_u8.data_ptr(), out.data_ptr(), B * H * W, CP)), "ffn_image_to_nhwc")
     return out
 
 
@@ -477,7 +496,8 @@ def nhwc_to_image(src, H, W, out=None):
     B, HW, ld = src.shape
     if out is None:
         out = torch.empty(B, 3, H, W, dtype=torch.float32, device=src.device)
-    L.check(lib.ffn_nhwc_to_image(_stream(), _dt(src), src.data_ptr(), out.data_ptr(), B, HW, ld), "ffn_nhwc_to_image")
+    L.check(_timed(f"nhwc_to_image_kernel<{_tname(src)}>", 0.0, B * HW * 3.0 * (src.element_size() + 4),
+                   lambda: lib.ffn_nhwc_to_image(_stream(), _dt(src), src.data_ptr(), out.data_ptr(), B, HW, ld)), "ffn_nhwc_to_image")
     return out
 
 
@@ -505,10 +525,24 @@ def tune_table_import(table):
     return lib.ffn_igemm_tune_import(buf, table.shape[0])
 
 
+def tune_table_clear():
+    return L.load().ffn_igemm_tune_clear()
+
+
+def tune_enable(on):
+    """timing-based tuning of unseen bf16 igemm shapes on / off for this process (off: the deterministic rule); returns the previous setting"""
+    return bool(L.load().ffn_igemm_tune_enable(1 if on else 0))
+
+
 def tune_table_save(path):
     torch.save(tune_table_export(), path)
 
 
 def tune_table_load(path):
-    import os
-    return tune_table_import(torch.load(path)) if os.path.exists(path) else 0
+    """a table written by tune_table_save.  weights_only: the file is data (a 2-D int32 tensor), never code; anything else is ignored."""
+    if not os.path.exists(path):
+        return 0
+    table = torch.load(path, weights_only=True, map_location="cpu")
+    if not torch.is_tensor(table) or table.ndim != 2 or table.dtype not in (torch.int32, torch.int64):
+        return 0
+    return tune_table_import(table)

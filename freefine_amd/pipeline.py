@@ -61,38 +61,59 @@ class FreeFinePipeline:
     # construction (freefine_batch_infer_2d.py:148-157)
     # ------------------------------------------------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, path, torch_dtype=torch.float32, device="cuda:0", seed=0, **kw):
+    def from_pretrained(cls, path, torch_dtype=torch.float32, device="cuda:0", seed=0, broadcast="auto", **kw):
         """`path` is either a HF-layout Stable-Diffusion folder (unet/, vae/ safetensors + config.json; tokenizer/,
         text_encoder/ loaded through transformers when present) or "synthetic:<unet preset>[:<vae preset>]" for
         seeded random weights of that architecture (no checkpoints exist in the build environment).
-        torch_dtype float32 -> exact-fp32 parity mode; float16/bfloat16 -> bf16 MFMA fast mode."""
+        torch_dtype float32 -> exact-fp32 parity mode; float16/bfloat16 -> bf16 MFMA fast mode.
+        In a torch.distributed job (`broadcast="auto"`: whenever a process group with more than one rank is initialised) only
+        rank 0 reads / generates the UNet and VAE weights; the other ranks receive them over RCCL straight into device memory
+        (freefine_amd.dist.broadcast_state; bf16 payload for the matrices in fast mode) -- the reference has every rank read
+        the checkpoint itself (freefine_batch_infer_2d.py:149)."""
+        from . import dist as FD
         dtype = torch.float32 if torch_dtype == torch.float32 else torch.bfloat16
+        shared = FD.active() if broadcast == "auto" else bool(broadcast)
+        lead = (not shared) or torch.distributed.get_rank() == 0
+        ust = vst = None
         if path.startswith("synthetic:"):
             parts = path.split(":")
             ucfg = UNetConfig.preset(parts[1])
             vcfg = VAEConfig.preset(parts[2] if len(parts) > 2 else ("tiny" if parts[1].startswith("tiny") else "sd"))
-            ust = synthetic_state(unet_param_shapes(ucfg), seed)
-            vst = synthetic_state(vae_param_shapes(vcfg), seed + 1)
+            if lead:
+                ust = synthetic_state(unet_param_shapes(ucfg), seed)
+                vst = synthetic_state(vae_param_shapes(vcfg), seed + 1)
             tok, enc = ByteTokenizer(), SyntheticTextEncoder(ucfg.cross_attention_dim)
             sched = DDIMScheduler()
         else:
-            ucd, ust = load_safetensors_dir(path, "unet")
-            vcd, vst = load_safetensors_dir(path, "vae")
+            import json
+            ucd = vcd = None
+            sc = {}
+            if lead:
+                ucd, ust = load_safetensors_dir(path, "unet")
+                vcd, vst = load_safetensors_dir(path, "vae")
+                sp = os.path.join(path, "scheduler", "scheduler_config.json")
+                if os.path.exists(sp):
+                    with open(sp) as f:
+                        sc = {k: v for k, v in json.load(f).items() if k in ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule",
+                                                                              "steps_offset", "set_alpha_to_one", "prediction_type")}
+            if shared:
+                ucd, vcd, sc = FD.broadcast_object((ucd, vcd, sc))
             ucfg = UNetConfig.from_diffusers(ucd)
             vcfg = VAEConfig(block_out_channels=tuple(vcd["block_out_channels"]), layers_per_block=vcd["layers_per_block"],
                              latent_channels=vcd["latent_channels"], norm_num_groups=vcd.get("norm_num_groups", 32),
                              scaling_factor=0.18215)
-            import json
-            sc = {}
-            sp = os.path.join(path, "scheduler", "scheduler_config.json")
-            if os.path.exists(sp):
-                with open(sp) as f:
-                    sc = {k: v for k, v in json.load(f).items() if k in ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule",
-                                                                          "steps_offset", "set_alpha_to_one", "prediction_type")}
             sched = DDIMScheduler(**sc)
             from transformers import CLIPTextModel, CLIPTokenizer
             tok = CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer"))
             enc = CLIPTextModel.from_pretrained(os.path.join(path, "text_encoder")).eval()
+        if shared:
+            if lead:        # the shape tables are defined on normalised names: rename legacy VAE keys before the names travel
+                ust, vst = normalize_state_dict(ust), normalize_state_dict(vst)
+                validate_state_dict(ust, unet_param_shapes(ucfg), "unet")
+                validate_state_dict(vst, vae_param_shapes(vcfg), "vae")
+            mdt = torch.float32 if dtype == torch.float32 else torch.bfloat16
+            ust = FD.broadcast_state(ust, unet_param_shapes(ucfg), device, matrix_dtype=mdt)
+            vst = FD.broadcast_state(vst, vae_param_shapes(vcfg), device, matrix_dtype=mdt)
         return cls.from_state(ucfg, ust, vcfg, vst, tok, enc, sched, dtype, device)
 
     @classmethod

@@ -73,7 +73,8 @@ int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
  * configurations on the caller's stream (this one call synchronises the stream and launches the kernel several times: `out` must
  * not alias `residual`) and caches the winner; FFN_IGEMM_TUNE=0 in the environment keeps the deterministic rule-based choice
  * (f32 always uses it).  Testing hooks: the number of bf16 configurations, and forcing one (-1 = off; returns the previous value). */
-/* explicit warm-up entry point: tunes (or looks up) the configuration for `d` now, exactly as the first ffn_igemm call would */
+/* explicit warm-up entry point: tunes (or looks up) the configuration for `d` now, exactly as the first ffn_igemm call would --
+ * it IS a full ffn_igemm call: `out` is written (several times while candidates are timed) and holds the winner's result */
 int ffn_igemm_tune(void* stream, int dtype, const ffn_igemm_desc* d);
 /* the tuned table as data: entries of ffn_igemm_tune_entry_ints() ints (problem key, configuration, K split).  export returns the
  * number of entries in the table (copies at most max_entries); import merges entries (unknown configurations are skipped) and returns
@@ -82,6 +83,15 @@ int ffn_igemm_tune(void* stream, int dtype, const ffn_igemm_desc* d);
 int ffn_igemm_tune_entry_ints(void);
 int ffn_igemm_tune_export(int* buf, int max_entries);
 int ffn_igemm_tune_import(const int* buf, int n_entries);
+/* Entries carry a stamp of the build that wrote them (table layout, configuration list, gfx950): import ignores foreign ones, and
+ * an imported entry is launched only after its (configuration, K split) was found among the candidates THIS build offers for the
+ * actual problem (workspace capacity, split legality, tile applicability); otherwise it is dropped and the problem re-tuned.
+ * ffn_igemm_tune_clear empties the table (returns the number of entries dropped); ffn_igemm_tune_enable(0) stops timing-based
+ * tuning in this process -- problems not in the table then take the deterministic rule (returns the previous setting).  A sharded
+ * run wanting bit-identical bf16 results on every rank: clear + import rank 0's table, then ffn_igemm_tune_enable(0). */
+int ffn_igemm_tune_clear(void);
+int ffn_igemm_tune_enable(int on);
+int ffn_igemm_tune_stamp(void);   /* first int of every entry this build exports */
 int ffn_igemm_num_configs(void);
 int ffn_igemm_force_config(int cfg);
 /* which tile (BM x BN) ffn_igemm dispatches for this problem -- lets a profiler name the kernel instantiation */

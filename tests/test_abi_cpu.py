@@ -28,23 +28,34 @@ def test_invalid_arguments_are_reported_not_crashed():
 
 
 def test_tune_table_roundtrip_and_rejects_foreign_entries(tmp_path):
-    """ffn_igemm_tune_export / _import: the tuned (problem -> configuration) table as data; entries naming a configuration this build
-    does not have are skipped (a table written by another build must not crash or mis-launch)."""
+    """ffn_igemm_tune_export / _import: the tuned (problem -> configuration) table as data.  Entry layout [stamp | key | cfg | splitk]:
+    entries with another build's stamp, an unknown configuration or a K split < 1 are skipped (a table written by another build must
+    not crash or mis-launch); clear / enable; a tune file that is not a 2-D integer tensor is ignored.  (Whether an
+    accepted entry FITS its problem is checked at its first launch, on the GPU: tests/test_ops_gpu.py.)"""
     import torch
     from freefine_amd import _lib, ops
     lib = _lib.load()
     w = lib.ffn_igemm_tune_entry_ints()
-    before = ops.tune_table_export()
-    t = torch.zeros(3, w, dtype=torch.int32)
-    t[:, 0] = torch.tensor([111, 222, 333]); t[:, 1] = 64; t[:, 2] = 128
-    t[:, -2] = torch.tensor([2, lib.ffn_igemm_num_configs() + 5, 0]); t[:, -1] = torch.tensor([1, 1, 0])      # entry 1: unknown cfg; entry 2: split 0
+    ops.tune_table_clear()
+    assert ops.tune_table_export().shape == (0, w)
+    t = torch.zeros(4, w, dtype=torch.int32)
+    t[:, 0] = lib.ffn_igemm_tune_stamp()
+    t[:, 1] = torch.tensor([111, 222, 333, 444]); t[:, 2] = 64; t[:, 3] = 128
+    t[:, -2] = torch.tensor([2, lib.ffn_igemm_num_configs() + 5, 0, 2]); t[:, -1] = torch.tensor([1, 1, 0, 1])      # entry 1: unknown cfg; entry 2: split 0
+    t[3, 0] ^= 0x100                                                                                                # entry 3: another build's stamp
     assert ops.tune_table_import(t) == 1
     after = ops.tune_table_export()
-    assert after.shape[0] == before.shape[0] + 1 and 111 in after[:, 0].tolist() and 222 not in after[:, 0].tolist()
+    assert after.shape[0] == 1 and after[0].tolist() == t[0].tolist()
     f = tmp_path / "tune.pt"
     ops.tune_table_save(str(f))
-    assert ops.tune_table_load(str(f)) == after.shape[0]
+    assert ops.tune_table_clear() == 1 and ops.tune_table_load(str(f)) == 1
     assert ops.tune_table_load(str(tmp_path / "missing.pt")) == 0
+    torch.save({"not": "a table"}, str(tmp_path / "bad.pt"))
+    assert ops.tune_table_load(str(tmp_path / "bad.pt")) == 0
+    torch.save(torch.zeros(5), str(tmp_path / "bad2.pt"))
+    assert ops.tune_table_load(str(tmp_path / "bad2.pt")) == 0
+    assert ops.tune_enable(False) is True and ops.tune_enable(True) is False
+    ops.tune_table_clear()
 
 
 def test_controller_plan_tables_host_logic():

@@ -18,21 +18,32 @@ rank, world = dist.get_rank(), dist.get_world_size()
 shapes = unet_param_shapes(UNetConfig.preset("tiny"))
 ref = synthetic_state(shapes, 0)
 got = FD.broadcast_state(ref if rank == 0 else None, shapes, "cpu", chunk_elems=1 << 20)
-assert set(got) == set(ref) and all(torch.equal(got[k], ref[k]) for k in ref)
+assert set(got) == set(ref) and all(torch.equal(got[k], ref[k]) and got[k].dtype == torch.float32 for k in ref)
+# bf16 payload for the weight matrices (fast mode): every rank receives RNE-rounded matrices, 1-D tensors stay fp32 exactly
+got16 = FD.broadcast_state(ref if rank == 0 else None, shapes, "cpu", chunk_elems=1 << 20, matrix_dtype=torch.bfloat16)
+for k in ref:
+    if ref[k].ndim >= 2:
+        assert got16[k].dtype == torch.bfloat16 and torch.equal(got16[k], ref[k].to(torch.bfloat16)), k
+    else:
+        assert got16[k].dtype == torch.float32 and torch.equal(got16[k], ref[k]), k
+assert FD.broadcast_object({"a": rank} if rank == 0 else None) == {"a": 0} and FD.active()
 n = 7
 mine = FD.shard_indices(n, rank, world)
 res = FD.gather_results([{"key": i, "rank": rank, "val": i * i} for i in mine])
 assert sorted(r["key"] for r in res) == list(range(n)), res
 # the igemm tuning table travels from rank 0 to everyone (identical tile / split-K choices on all ranks)
 from freefine_amd import ops
+from freefine_amd import _lib
 w = ops.tune_table_export().shape[1]
-if rank == 0:
-    t = torch.zeros(3, w, dtype=torch.int32)
-    t[:, 0] = torch.tensor([4096, 8192, 98304]); t[:, 1] = 320; t[:, 2] = 320; t[:, -2] = torch.tensor([1, 6, 13]); t[:, -1] = 1
-    assert ops.tune_table_import(t) == 3
+t = torch.zeros(3, w, dtype=torch.int32)
+t[:, 0] = _lib.load().ffn_igemm_tune_stamp()
+t[:, 1] = torch.tensor([4096, 8192, 98304]) + rank; t[:, 2] = 320; t[:, 3] = 320; t[:, -2] = torch.tensor([1, 6, 13]); t[:, -1] = 1
+assert ops.tune_table_import(t) == 3           # every rank has "tuned" its own (different) keys before the sync
 n_tab = FD.sync_tune_table()
 tab = ops.tune_table_export()
-assert tab.shape[0] == 3 and sorted(tab[:, 0].tolist()) == [4096, 8192, 98304] and sorted(tab[:, -2].tolist()) == [1, 6, 13], tab
+# rank 0's table REPLACES the local one (no rank-local leftovers), and timing-based tuning is frozen on every rank
+assert n_tab == 3 and tab.shape[0] == 3 and sorted(tab[:, 1].tolist()) == [4096, 8192, 98304] and sorted(tab[:, -2].tolist()) == [1, 6, 13], tab
+assert ops.tune_enable(True) is False
 if rank == 0:
     print("DIST_OK", len(res))
 dist.destroy_process_group()

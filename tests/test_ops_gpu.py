@@ -588,3 +588,128 @@ def test_every_bf16_igemm_configuration(gpu):
                 assert relerr(out, ref) < tol(dt), (cfg, "conv-halo-shapes", H, W)
     finally:
         lib.ffn_igemm_force_config(-1)
+
+
+def _ref_attention_gpu(q, k, v, heads, scale, allowed=None):
+    """ref_attention evaluated in fp64 on the GPU by plain torch (the production shapes: S = 4096 x 4096 scores per head)."""
+    S, Cc = q.shape
+    d = Cc // heads
+    out = torch.zeros(S, Cc, dtype=torch.float64, device=q.device)
+    for h in range(heads):
+        sl = slice(h * d, (h + 1) * d)
+        s = scale * q[:, sl] @ k[:, sl].t()
+        if allowed is not None and allowed[h] is not None:
+            a = allowed[h]
+            s = torch.where(a, s, torch.full_like(s, -1e300))
+            s[~a.any(dim=1)] = 0.0
+        out[:, sl] = torch.softmax(s, dim=-1) @ v[:, sl]
+    return out
+
+
+def _production_masks(S, kind, g):
+    """per-key source mask / per-query target mask at a production sequence length: 'rect' = rectangles on the sqrt(S) grid (whole
+    64-key tiles masked or unmasked, the shape GeoBench masks have), 'rand' = random bytes (every tile mixed)."""
+    n = int(math.isqrt(S))
+    if kind == "rect":
+        src, tgt = torch.zeros(n, n, dtype=torch.uint8), torch.zeros(n, n, dtype=torch.uint8)
+        src[n * 25 // 64:n * 37 // 64, n * 12 // 64:n * 25 // 64] = 1
+        tgt[n * 25 // 64:n * 37 // 64, n * 20 // 64:n * 33 // 64] = 1
+        return src.flatten(), tgt.flatten()
+    return (torch.rand(S, generator=g) > 0.6).to(torch.uint8), (torch.rand(S, generator=g) > 0.5).to(torch.uint8)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hook", ["edit", "bggen"])
+@pytest.mark.parametrize("kind", ["rect", "rand"])
+@pytest.mark.parametrize("S,heads", [(4096, 5), (1024, 10)])
+def test_attention_tca_production_shapes(gpu, dtype, hook, kind, S, heads):
+    """The TCA pass tables of the guided loop at the shapes BASELINE config 2 runs them (SD-2.1: S = 4096 / h = 5 and S = 1024 / h = 10,
+    d = 64, B = 4 rows [u_e, u_r, c_e, c_r]) against the fp64 statement of /root/reference/src/utils/attention.py:1043-1091 (edit) and
+    :1284-1324 (bg): reference-row K/V, per-key mask, per-query selector (edit), tiled-head rule on odd / even j = b * heads + head,
+    context-guidance blend from a device scalar.  In bf16 this is attn_pp_kernel<true> with its 4-slot LDS rings wrapping 16 / 4 times
+    per query block; in f32 the exact-fp32 attn_kernel."""
+    import ctypes
+    from freefine_amd import _lib, ops
+    from freefine_amd._lib import ATT_HEAD_RULE
+    g = torch.Generator().manual_seed(S + heads)
+    B, D = 4, 64
+    Cc = heads * D
+    q = rnd((B, S, Cc), dtype, gpu, g)
+    k = rnd((B, S, Cc), dtype, gpu, g)
+    v = rnd((B, S, Cc), dtype, gpu, g)
+    vt = ops.transpose(v)
+    src, tgt = _production_masks(S, kind, g)
+    cg = 0.35
+    cg_dev = torch.tensor([cg], dtype=torch.float32, device=gpu)
+    scale = D ** -0.5
+    ref_rows = [1, 1, 3, 3]
+    if hook == "edit":
+        kmask, qsel = src.to(gpu), tgt.to(gpu)
+        p_ref = [ops.AttnEntrySpec(b, ref_rows[b], 0.0, 1.0, kmask=kmask, qsel=qsel, flags=ATT_HEAD_RULE) for b in range(B)]
+    else:       # keys allowed OUTSIDE the hole, no query-side blend
+        kmask = (1 - src).to(gpu)
+        p_ref = [ops.AttnEntrySpec(b, ref_rows[b], 0.0, 1.0, kmask=kmask, flags=ATT_HEAD_RULE) for b in range(B)]
+    p_self = [ops.AttnEntrySpec(b, b, 1.0, -1.0) for b in range(B)]
+    out = ops.attention(q, k, vt, heads, scale, [p_ref, p_self], w_dev=cg_dev)
+    if dtype == torch.bfloat16:          # the kernel the bench runs for these launches
+        d = _lib.AttnDesc()
+        d.Bo, d.S, d.Sk, d.heads, d.D, d.npass, d.ldo, d.w_dev = B, S, S, heads, D, 2, Cc, cg_dev.data_ptr()
+        for b, sp in enumerate(p_ref):
+            e = d.e[b]
+            e.q_row, e.kv_row, e.w_const, e.w_slope, e.kmask, e.flags = sp.q_row, sp.kv_row, sp.w_const, sp.w_slope, sp.kmask.data_ptr(), sp.flags
+        for b, sp in enumerate(p_self):
+            e = d.e[_lib.ATT_MAXB + b]
+            e.q_row, e.kv_row, e.w_const, e.w_slope = sp.q_row, sp.kv_row, sp.w_const, sp.w_slope
+        name = ctypes.create_string_buffer(160)
+        _lib.load().ffn_attn_kernel_name(1, ctypes.byref(d), name, 160)
+        assert b"attn_pp_kernel<true>" in name.value, name.value
+    qd, kd, vd = q.double(), k.double(), v.double()
+    sg, tg = src.to(gpu), tgt.to(gpu)
+    if hook == "edit":
+        a_even = (sg[None, :] != 0) == (tg[:, None] != 0)
+    else:
+        a_even = (sg[None, :] == 0).expand(S, S)
+    worst = 0.0
+    for b in range(B):
+        allowed = [a_even if (b * heads + h) % 2 == 0 else None for h in range(heads)]
+        r = _ref_attention_gpu(qd[b], kd[ref_rows[b]], vd[ref_rows[b]], heads, scale, allowed)
+        s_ = _ref_attention_gpu(qd[b], kd[b], vd[b], heads, scale)
+        worst = max(worst, relerr(out[b], cg * r + (1 - cg) * s_))
+    print(f"TCA {hook} {kind} S={S} h={heads} {dtype}: max |diff| / max |ref| = {worst:.2e}")
+    assert worst < tol(dtype)
+
+
+def test_ragged_m_tail_rows_are_not_written(gpu):
+    """The ping-pong kernel's bf16 / GEGLU / residual epilogues leave rows >= M of a tail tile to the buffer descriptor's range check
+    (igemm_p8.h store_rows).  Canary: `out` (and the residual) are the first M rows of LARGER buffers filled with a sentinel; after the
+    launch every row >= M must still hold it -- for each ping-pong configuration forced in turn, M not a multiple of the tile height."""
+    from freefine_amd import _lib as L
+    from freefine_amd import ops
+    lib = L.load()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(17)
+    M, K, guard = 256 * 9 + 72, 320, 512
+    names = []
+    try:
+        for cfg in range(lib.ffn_igemm_num_configs()):
+            lib.ffn_igemm_force_config(cfg)
+            for (N, geglu, with_res) in [(320, False, True), (640, False, False), (1280, True, False), (512, False, True)]:
+                x = rnd((M, K), dt, gpu, g)
+                w = rnd((N, K), dt, gpu, g, K ** -0.5)
+                b = rnd((N,), torch.float32, gpu, g)
+                n_out = N // 2 if geglu else N
+                big = torch.full((M + guard, n_out), 7.0, dtype=dt, device=gpu)
+                out = big[:M]
+                rbig = rnd((M + guard, n_out), dt, gpu, g)
+                if geglu:
+                    wp, bp = ops.pack_geglu(w, b, dt)
+                    ops.linear(x, wp, bp, K=K, geglu=True, out=out)
+                    y = x.double() @ w.double().t() + b.double()
+                    ref = y[:, :n_out] * F.gelu(y[:, n_out:])
+                else:
+                    ops.linear(x, ops.pack_linear(w, dt), b, K=K, out=out, residual=rbig[:M] if with_res else None)
+                    ref = x.double() @ w.double().t() + b.double() + (rbig[:M].double() if with_res else 0.0)
+                assert relerr(out, ref) < tol(dt), (cfg, N)
+                assert (big[M:] == 7.0).all(), (cfg, N, geglu, with_res)
+    finally:
+        lib.ffn_igemm_force_config(-1)

@@ -56,22 +56,23 @@ def test_unet_other_latent_sizes(gpu, hw):
     assert relerr(out, ref) < 6e-2
 
 
-def masks128(kind="uint8"):
-    src = rect_mask(128, 128, 24, 72, 16, 64)
-    tgt = rect_mask(128, 128, 40, 100, 56, 120)
-    src2 = rect_mask(128, 128, 80, 120, 8, 48)
-    tgt2 = rect_mask(128, 128, 8, 40, 72, 104)
+def masks128(kind="uint8", size=128):
+    k = size // 128
+    src = rect_mask(size, size, 24 * k, 72 * k, 16 * k, 64 * k)
+    tgt = rect_mask(size, size, 40 * k, 100 * k, 56 * k, 120 * k)
+    src2 = rect_mask(size, size, 80 * k, 120 * k, 8 * k, 48 * k)
+    tgt2 = rect_mask(size, size, 8 * k, 40 * k, 72 * k, 104 * k)
     f = (lambda m: torch.tensor(m.astype(np.float32))) if kind == "float" else (lambda m: torch.tensor(m))
     return f(src), f(tgt), f(src2), f(tgt2)
 
 
-def setup_pair(hook, method, gpu, dtype, name="tiny", cg=0.37, kind="uint8"):
+def setup_pair(hook, method, gpu, dtype, name="tiny", cg=0.37, kind="uint8", size=128, pair=None):
     from freefine_amd.attention import (Attention_Modulator, register_attention_control, register_attention_control_4bggen,
                                         register_attention_control_compose)
     from oracle.attention_modulation import Modulator
     from types import SimpleNamespace
-    onet, hnet = build(name, dtype, gpu)
-    src, tgt, src2, tgt2 = masks128(kind)
+    onet, hnet = pair if pair is not None else build(name, dtype, gpu)
+    src, tgt, src2, tgt2 = masks128(kind, size)
     om = Modulator(hook, num_att_layers=len(onet.attention_modules()))
     onet.set_modulator(om)
     hc = Attention_Modulator(start_layer=10)
@@ -150,3 +151,32 @@ def test_unet_full_size_bf16_fast_mode_vs_oracle(gpu):
     err = relerr(out, ref)
     print(f"bf16 fast mode, full-size sd21-base @64x64: max |diff| / max |ref| = {err:.3e}")
     assert err < 6e-2
+
+
+@pytest.mark.parametrize("hook", ["edit", "bggen"])
+def test_unet_full_size_modulated_64x64(gpu, hook):
+    """SD-2.1-base topology at the 64x64 latent with the attention-modulation hooks ON (TCA in blocks 10-15 at S = 4096 / 1024 with
+    512^2 masks, local cross-attention in all 16 blocks), B = 4 rows [u_e, u_r, c_e, c_r]: the guided forward of BASELINE config 2
+    against the CPU oracle (pinned to the reference's hooks by G1/G2/G5).  fp32 parity mode <= 2e-4 of the output scale; the bf16
+    fast mode runs the same forward through attn_pp_kernel<true> / xattn_mp_kernel / igemm_pp_kernel and its deviation is printed."""
+    from oracle import sd_unet
+    torch.set_num_threads(max(8, min(32, torch.get_num_threads())))
+    onet = sd_unet.init_unet(sd_unet.unet_config("sd21-base"), seed=0)
+    D = onet.cfg.cross_attention_dim
+    x, enc = rng_tensor(31, (4, 4, 64, 64)), rng_tensor(32, (4, 77, D))
+    ref = None
+    from freefine_amd.config import UNetConfig
+    from freefine_amd.unet import HipUNet
+    for dtype, tol in ((torch.float32, 2e-4), (torch.bfloat16, 6e-2)):
+        hnet = HipUNet(UNetConfig.preset("sd21-base"), onet.state_dict(), dtype=dtype, device=gpu)
+        _, _, om, hc = setup_pair(hook, "tca", gpu, dtype, name="sd21-base", size=512, pair=(onet, hnet))
+        if ref is None:
+            ref = onet(x, torch.tensor(481), enc)
+            assert (om.cur_att_layer, om.cur_step) == (0, 1)
+        out = hnet(x.to(gpu), 481, enc.to(gpu))
+        err = relerr(out, ref)
+        print(f"full-size sd21-base @64x64, hook={hook}/tca, {dtype}: max |diff| / max |ref| = {err:.3e}")
+        assert err < tol, (hook, dtype)
+        assert (hc.cur_att_layer, hc.cur_step) == (0, 1)
+        del hnet
+        torch.cuda.empty_cache()
