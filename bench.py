@@ -78,10 +78,9 @@ def build_model(args, device, rank, world):
         vst = FD.broadcast_state(synthetic_state(vae_param_shapes(vcfg), 1) if rank == 0 else None, vae_param_shapes(vcfg), device, matrix_dtype=mdt)
     else:
         ust, vst = synthetic_state(unet_param_shapes(ucfg), 0), synthetic_state(vae_param_shapes(vcfg), 1)
-    if args.dtype == "bf16x3":
-        raise NotImplementedError("bf16x3 mode is not built in this tree yet")
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model = FreeFinePipeline.from_state(ucfg, ust, vcfg, vst, ByteTokenizer(), SyntheticTextEncoder(ucfg.cross_attention_dim), None, dtype, device)
+    model = FreeFinePipeline.from_state(ucfg, ust, vcfg, vst, ByteTokenizer(), SyntheticTextEncoder(ucfg.cross_attention_dim), None, dtype, device,
+                                        x3=args.dtype == "bf16x3")
     model.scheduler = DDIMScheduler.from_config(model.scheduler.config)
     controller = Attention_Modulator(start_layer=10)
     model.controller = controller
@@ -269,7 +268,7 @@ def main():
     ap.add_argument("--cpu-skip-vae", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-parity", action="store_true", help="skip the parity-mode leg (f32 throughput + the headline mode's latent deviation)")
-    ap.add_argument("--parity-modes", default="f32", help="comma list; the first one is the reference of the deviation figures")
+    ap.add_argument("--parity-modes", default="f32,bf16x3", help="comma list; the first one is the reference of the deviation figures")
     ap.add_argument("--parity-batch", type=int, default=4)
     args = ap.parse_args()
 

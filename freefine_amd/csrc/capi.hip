@@ -258,23 +258,29 @@ static bool is_pp_cfg(int cfg) { return cfg >= CFG_PP_256x320 && cfg <= CFG_PP_1
 static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn, int splitk = 1) {
     const long lim = (1l << 31) - 4096;
     if (d.K % 64 != 0 || d.K < 128 || d.N % bn != 0 || d.M < bm) return false;
+    const int osz = d.x3 ? 4 : 2;                                  // bytes per output / residual element
+    if (d.x3 && ((d.K / 3) % 64 != 0 || d.a_lo % 8 != 0)) return false;      // whole 64-element chunks in each of the three segments
     if (splitk > 1) {       // split-K: raw fp32 slabs + igemm_splitk_reduce_kernel (which applies every plain epilogue option)
         if (!can_split(d) || (d.K / 64) % splitk != 0 || d.K / 64 / splitk < 2 || (long)splitk * d.M * d.N * 4 > d.ws_bytes || (long)splitk * d.M * d.N * 4 >= lim) return false;
     } else {
-        if (d.alpha != 1.0f || (d.flags & ~FFN_IG_GEGLU)) return false;
+        if (d.alpha != 1.0f || (d.flags & ~(FFN_IG_GEGLU | (d.x3 ? FFN_IG_OUT_F32 : 0)))) return false;
         if ((d.flags & FFN_IG_GEGLU) && bn != 256) return false;
         if (d.rowbias && d.rows_per_batch < 128) return false;      // a wave's rows (bm / 2) may straddle two images, not three
     }
     long a_bytes;
     if (d.conv) {
-        if (d.Cin % 64 != 0 || d.K != 9 * d.Cin || d.Cin / 64 * 9 * (d.Cin / 64) >= 65536) return false;
-        a_bytes = (long)(d.M / (d.Hout * d.Wout)) * d.Hin * d.Win * d.Cin * 2;
+        const int pix = d.x3 ? d.lda : d.Cin;                      // elements per input pixel
+        if (d.Cin % 64 != 0 || d.K != (d.x3 ? 27 : 9) * d.Cin) return false;
+        if (d.x3 ? (d.Cin / 64 >= 100) : (d.Cin / 64 * 9 * (d.Cin / 64) >= 65536)) return false;      // exactness range of the tap reciprocal
+        a_bytes = (long)(d.M / (d.Hout * d.Wout)) * d.Hin * d.Win * pix * 2;
         if (2 * d.Hin + 2 >= 32768 || 2 * d.Win + 2 >= 32768) return false;
+        if (a_bytes + 256l * pix * 2 >= lim) return false;
     } else {
         a_bytes = (long)d.M * d.lda * 2;
+        if (a_bytes + 256l * d.lda * 2 >= lim) return false;
     }
-    if (a_bytes + (256l * (d.conv ? d.Cin : d.lda) * 2) >= lim || (long)d.N * d.Kpad * 2 >= lim || (long)(d.M + 256) * d.ldo * 2 >= lim) return false;
-    if (d.residual && (long)(d.M + 256) * d.ldr * 2 >= lim) return false;
+    if ((long)d.N * d.Kpad * 2 >= lim || (long)(d.M + 256) * d.ldo * osz >= lim) return false;
+    if (d.residual && (long)(d.M + 256) * d.ldr * osz >= lim) return false;
     return true;
 }
 // LDS bytes of ONE halo buffer of the halo conv kernel for tile height bm, or 0 if the problem does not fit the kernel: 3x3,
@@ -295,9 +301,12 @@ static int halo_bytes_for(const ffn_igemm_desc& d, int bm) {
     if (nq > 4 * 16) return 0;                      // 4 halo wave-instructions per wave, 16 waves
     return nq * 8 * 128;
 }
-template <int AMODE>
+// X3 (split-bf16, FFN_BF16X3) problems run the generic 64x64 / 128x64 / 128x128 tiles (recomputing loader) and the ping-pong tiles
+static bool x3_cfg(int cfg) { return cfg == CFG_64x64 || cfg == CFG_128x64 || cfg == CFG_128x128_8 || is_pp_cfg(cfg); }
+template <int AMODE, bool X3 = false>
 static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) {
     const IgCfgInfo& c = kCfg[ch.cfg];
+    if (X3 && !x3_cfg(ch.cfg)) return fail(FFN_EINVAL, "igemm: configuration %d is not built for split-bf16 problems", ch.cfg);
     const int ntiles = ((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn);
     const int lds = 2 * (c.bm + c.bn) * 128, threads = 64 * c.nwm * c.nwn;
     int rc = FFN_OK;
@@ -307,8 +316,13 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
     const bool fastk = (d.conv ? d.Cin % 64 == 0 : d.K % 64 == 0) && (long)d.K * 2 + 256 <= (long)sizeof(g_zero_page);
 #define FFN_CFG_CASE(ID, BM_, BN_, WM_, WN_)                                                                                               \
     case ID:                                                                                                                        \
-        rc = fastk ? launch_igemm_kernel(igemm_glds_kernel<bf16, BM_, BN_, AMODE, true, 2, WM_, WN_, true>, lds, s, d, ntiles, ch.splitk, threads, true)  \
-                   : launch_igemm_kernel(igemm_glds_kernel<bf16, BM_, BN_, AMODE, true, 2, WM_, WN_, false>, lds, s, d, ntiles, ch.splitk, threads, true); \
+        if constexpr (X3) {                                                                                                         \
+            if constexpr (ID == CFG_64x64 || ID == CFG_128x64 || ID == CFG_128x128_8)                                               \
+                rc = launch_igemm_kernel(igemm_glds_kernel<bf16, BM_, BN_, AMODE, true, 2, WM_, WN_, false, true>, lds, s, d, ntiles, ch.splitk, threads, true); \
+        } else {                                                                                                                    \
+            rc = fastk ? launch_igemm_kernel(igemm_glds_kernel<bf16, BM_, BN_, AMODE, true, 2, WM_, WN_, true>, lds, s, d, ntiles, ch.splitk, threads, true)  \
+                       : launch_igemm_kernel(igemm_glds_kernel<bf16, BM_, BN_, AMODE, true, 2, WM_, WN_, false>, lds, s, d, ntiles, ch.splitk, threads, true); \
+        }                                                                                                                           \
         break;
     switch (ch.cfg) {
         FFN_CFG_CASE(CFG_64x64, 64, 64, 2, 2)
@@ -331,7 +345,7 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
             (void)hipGetLastError();
 #define FFN_PP_LAUNCH(BM_, BN_, RES_, GEGLU_)                                              \
     do {                                                                                   \
-        auto kern = igemm_pp_kernel<BM_, BN_, AMODE, RES_, GEGLU_>;                        \
+        auto kern = igemm_pp_kernel<BM_, BN_, AMODE, RES_, GEGLU_, false, false, X3>;      \
         if ((rc = set_lds(kern, pplds))) return rc;                                        \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pplds, s, d, 1);                   \
     } while (0)
@@ -353,7 +367,7 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
     } while (0)
 #define FFN_PP_SPLIT(BM_, BN_)                                                             \
     do {                                                                                   \
-        auto kern = igemm_pp_kernel<BM_, BN_, AMODE, false, false, true>;                  \
+        auto kern = igemm_pp_kernel<BM_, BN_, AMODE, false, false, true, false, X3>;       \
         if ((rc = set_lds(kern, pplds))) return rc;                                        \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pplds, s, d, ch.splitk);           \
     } while (0)
@@ -364,7 +378,8 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
                 else FFN_PP_SPLIT(192, 256);
                 if ((rc = check_launch("igemm(ping-pong, split-K)"))) return rc;
                 const long nq = (long)d.M * (d.N / 4);
-                LAUNCH(igemm_splitk_reduce_kernel<bf16>, dim3(grid_for(nq)), dim3(256), 0, s, d, ch.splitk);
+                if constexpr (X3) LAUNCH(igemm_splitk_reduce_kernel<float>, dim3(grid_for(nq)), dim3(256), 0, s, d, ch.splitk);
+                else LAUNCH(igemm_splitk_reduce_kernel<bf16>, dim3(grid_for(nq)), dim3(256), 0, s, d, ch.splitk);
                 return check_launch("igemm_splitk_reduce");
             }
             if (c.bm == 256) FFN_PP_TILE(256);
@@ -378,7 +393,7 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
         case CFG_H_256x128:
         case CFG_H_256x256:
         case CFG_H_128x128:
-            if constexpr (AMODE == AMODE_CONV3) {
+            if constexpr (AMODE == AMODE_CONV3 && !X3) {
                 const int hb = halo_bytes_for(d, c.bm);
                 if (hb <= 0 || ch.splitk != 1) return fail(FFN_EINVAL, "igemm: halo kernel not applicable");
                 const int hlds = 2 * hb + 2 * c.bn * 128;
@@ -410,7 +425,8 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
 #undef FFN_CFG_CASE
     if (rc || ch.splitk == 1) return rc;
     const long nq = (long)d.M * (d.N / 4);
-    LAUNCH(igemm_splitk_reduce_kernel<bf16>, dim3(grid_for(nq)), dim3(256), 0, s, d, ch.splitk);
+    if constexpr (X3) LAUNCH(igemm_splitk_reduce_kernel<float>, dim3(grid_for(nq)), dim3(256), 0, s, d, ch.splitk);
+    else LAUNCH(igemm_splitk_reduce_kernel<bf16>, dim3(grid_for(nq)), dim3(256), 0, s, d, ch.splitk);
     return check_launch("igemm_splitk_reduce");
 }
 
@@ -433,6 +449,7 @@ static TuneKey tune_key(const ffn_igemm_desc& d) {
     if (d.conv) { k.Cin = d.Cin; k.Hin = d.Hin; k.Win = d.Win; k.stride = d.stride; k.upsample = d.upsample; k.pad = d.pad; k.Hout = d.Hout; k.Wout = d.Wout; }
     k.Kpad = d.Kpad;
     k.ldr = d.residual ? d.ldr : 0;
+    k.dtype = d.x3 ? FFN_BF16X3 : FFN_BF16;
     k.ptrs = (d.bias ? 1 : 0) | (d.rowbias ? 2 : 0) | (d.residual ? 4 : 0) | (d.ws && d.ws_bytes > 0 ? 8 : 0);
     const long per = (long)d.M * d.N * 4;
     k.wslabs = d.ws ? (int)(d.ws_bytes / per > 1024 ? 1024 : d.ws_bytes / per) : 0;      // how many split-K slabs the workspace holds
@@ -473,7 +490,7 @@ static IgChoice heuristic_choice(const ffn_igemm_desc& d) {
     igemm_exec_cfg(FFN_BF16, d, bm, bn, sk, &ns, &nw);
     int cfg = CFG_64x64;
     if (bm == 128 && bn == 64) cfg = CFG_128x64;
-    if (bm == 128 && bn == 128) cfg = nw == 16 ? CFG_128x128_16 : CFG_128x128_8;
+    if (bm == 128 && bn == 128) cfg = (nw == 16 && !d.x3) ? CFG_128x128_16 : CFG_128x128_8;
     return IgChoice{cfg, sk};
 }
 static int candidates_for(const ffn_igemm_desc& d, IgChoice* out, int cap) {
@@ -484,6 +501,7 @@ static int candidates_for(const ffn_igemm_desc& d, IgChoice* out, int cap) {
     const long per = (long)d.M * d.N * 4;
     for (int cfg = 0; cfg < CFG_COUNT; ++cfg) {
         const IgCfgInfo& c = kCfg[cfg];
+        if (d.x3 && !x3_cfg(cfg)) continue;
         if ((cfg == CFG_128x320 || cfg == CFG_128x160 || cfg == CFG_192x320) && (d.flags & FFN_IG_GEGLU)) continue;   // odd number of column blocks per wave
         if (is_halo_cfg(cfg)) {
             const int hb = halo_bytes_for(d, c.bm);
@@ -543,14 +561,14 @@ extern "C" int ffn_igemm_force_config(int cfg) {
     g_force_cfg = (cfg >= 0 && cfg < CFG_COUNT) ? cfg : -1;
     return prev;
 }
-template <int AMODE>
+template <int AMODE, bool X3 = false>
 static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
     if (g_force_cfg >= 0) {
         IgChoice cand[40];
         const int nc = candidates_for(d, cand, 40);
         for (int i = 0; i < nc; ++i)
-            if (cand[i].cfg == g_force_cfg) return launch_bf16_cfg<AMODE>(s, d, cand[i]);
-        return launch_bf16_cfg<AMODE>(s, d, heuristic_choice(d));     // not valid for this problem
+            if (cand[i].cfg == g_force_cfg) return launch_bf16_cfg<AMODE, X3>(s, d, cand[i]);
+        return launch_bf16_cfg<AMODE, X3>(s, d, heuristic_choice(d));     // not valid for this problem
     }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
@@ -571,25 +589,25 @@ static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
                 if (ok) it->second.validated = true;
                 else g_tuned.erase(it), it = g_tuned.end();
             }
-            if (it != g_tuned.end()) return launch_bf16_cfg<AMODE>(s, d, it->second.ch);
+            if (it != g_tuned.end()) return launch_bf16_cfg<AMODE, X3>(s, d, it->second.ch);
         }
     }
-    if (!tune_enabled() || cap != hipStreamCaptureStatusNone || aliased) return launch_bf16_cfg<AMODE>(s, d, heuristic_choice(d));
+    if (!tune_enabled() || cap != hipStreamCaptureStatusNone || aliased) return launch_bf16_cfg<AMODE, X3>(s, d, heuristic_choice(d));
     std::lock_guard<std::mutex> lk(g_tune_mu);       // one tuning at a time
     IgChoice cand[40];
     const int nc = candidates_for(d, cand, 40);
     hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return launch_bf16_cfg<AMODE>(s, d, cand[0]);
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return launch_bf16_cfg<AMODE, X3>(s, d, cand[0]);
     IgChoice best = cand[0];
     float best_ms = 1e30f;
     const int reps = 3;
     for (int i = 0; i < nc; ++i) {
-        int rc = launch_bf16_cfg<AMODE>(s, d, cand[i]);      // warm (LDS opt-in, code load)
+        int rc = launch_bf16_cfg<AMODE, X3>(s, d, cand[i]);      // warm (LDS opt-in, code load)
         if (rc) continue;
         float ms = 1e30f;
         for (int round = 0; round < 2 && !rc; ++round) {       // min of two timed groups: one noisy group must not pick the configuration
             (void)hipEventRecord(e0, s);
-            for (int r = 0; r < reps && !rc; ++r) rc = launch_bf16_cfg<AMODE>(s, d, cand[i]);
+            for (int r = 0; r < reps && !rc; ++r) rc = launch_bf16_cfg<AMODE, X3>(s, d, cand[i]);
             (void)hipEventRecord(e1, s);
             if (rc || hipEventSynchronize(e1) != hipSuccess) { rc = rc ? rc : FFN_EHIP; break; }
             float t = 0.f;
@@ -606,7 +624,7 @@ static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
     if (verbose)
         fprintf(stderr, "[ffn tune] %s M=%d N=%d K=%d flags=%d -> %dx%d split %d (%.1f us, %d candidates)\n", d.conv ? "conv" : "dense", d.M, d.N,
                 d.K, d.flags, kCfg[best.cfg].bm, kCfg[best.cfg].bn, best.splitk, best_ms * 1e3f / reps, nc);
-    return launch_bf16_cfg<AMODE>(s, d, best);       // the output now holds the winner's result
+    return launch_bf16_cfg<AMODE, X3>(s, d, best);       // the output now holds the winner's result
 }
 // ---- the tuned table as data: export / import (persist it across processes, broadcast rank 0's table so that every rank of a
 // sharded run launches the same configurations -- bf16 results then are bit-identical across ranks)
@@ -668,11 +686,20 @@ static bool tuned_lookup(const ffn_igemm_desc& d, IgChoice* ch) {
 }
 
 static bool pp_trans_tile(const ffn_igemm_desc& d, int* bm, int* bn);
-extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d, char* buf, int len) {
-    REQUIRE(d && buf && len > 0, "igemm_kernel_name: null argument");
+static ffn_igemm_desc x3_view(const ffn_igemm_desc& d);
+extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d0, char* buf, int len) {
+    REQUIRE(d0 && buf && len > 0, "igemm_kernel_name: null argument");
     int bm, bn, sk, ns, nw;
     IgChoice ch;
-    if (dtype == FFN_BF16 && !(d->flags & FFN_IG_OUT_TRANSPOSED)) {      // the tuned (or, untuned, rule-based) bf16 configuration
+    const bool x3 = dtype == FFN_BF16X3;
+    const ffn_igemm_desc dd = x3 ? x3_view(*d0) : *d0;
+    const ffn_igemm_desc* d = &dd;
+    if (x3 && (d->flags & FFN_IG_OUT_TRANSPOSED)) {
+        igemm_plan_for(FFN_BF16, *d, &bm, &bn, &sk);
+        snprintf(buf, len, "void igemm_glds_kernel<bf16, %d, %d, 0, false, 2, 2, 2, false, true>(ffn_igemm_desc)", bm, bn);
+        return FFN_OK;
+    }
+    if ((dtype == FFN_BF16 || x3) && !(d->flags & FFN_IG_OUT_TRANSPOSED)) {      // the tuned (or, untuned, rule-based) bf16 configuration
         if (!tuned_lookup(*d, &ch)) ch = heuristic_choice(*d);
         const IgCfgInfo& c = kCfg[ch.cfg];
         if (is_halo_cfg(ch.cfg)) {
@@ -681,17 +708,18 @@ extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d, char* b
         }
         if (is_pp_cfg(ch.cfg)) {
             const bool split = ch.splitk > 1;
-            snprintf(buf, len, "void igemm_pp_kernel<%d, %d, %d, %s, %s, %s, false>(ffn_igemm_desc, int)", c.bm, c.bn, d->conv ? 1 : 0,
-                     (!split && d->residual) ? "true" : "false", (!split && (d->flags & FFN_IG_GEGLU)) ? "true" : "false", split ? "true" : "false");
+            snprintf(buf, len, "void igemm_pp_kernel<%d, %d, %d, %s, %s, %s, false, %s>(ffn_igemm_desc, int)", c.bm, c.bn, d->conv ? 1 : 0,
+                     (!split && d->residual) ? "true" : "false", (!split && (d->flags & FFN_IG_GEGLU)) ? "true" : "false", split ? "true" : "false",
+                     x3 ? "true" : "false");
             return FFN_OK;
         }
-        const bool fastk = (d->conv ? d->Cin % 64 == 0 : d->K % 64 == 0) && (long)d->K * 2 + 256 <= (long)sizeof(g_zero_page);
-        snprintf(buf, len, "void igemm_glds_kernel<bf16, %d, %d, %d, true, 2, %d, %d, %s>(ffn_igemm_desc)", c.bm, c.bn, d->conv ? 1 : 0, c.nwm, c.nwn,
-                 fastk ? "true" : "false");
+        const bool fastk = !x3 && (d->conv ? d->Cin % 64 == 0 : d->K % 64 == 0) && (long)d->K * 2 + 256 <= (long)sizeof(g_zero_page);
+        snprintf(buf, len, "void igemm_glds_kernel<bf16, %d, %d, %d, true, 2, %d, %d, %s, %s>(ffn_igemm_desc)", c.bm, c.bn, d->conv ? 1 : 0, c.nwm, c.nwn,
+                 fastk ? "true" : "false", x3 ? "true" : "false");
         return FFN_OK;
     }
     if (dtype == FFN_BF16 && (d->flags & FFN_IG_OUT_TRANSPOSED) && !d->conv && pp_trans_tile(*d, &bm, &bn)) {
-        snprintf(buf, len, "void igemm_pp_kernel<%d, %d, 0, false, false, false, true>(ffn_igemm_desc, int)", bm, bn);
+        snprintf(buf, len, "void igemm_pp_kernel<%d, %d, 0, false, false, false, true, false>(ffn_igemm_desc, int)", bm, bn);
         return FFN_OK;
     }
     igemm_plan_for(dtype, *d, &bm, &bn, &sk);
@@ -701,7 +729,7 @@ extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d, char* b
     if (ns == 1) snprintf(buf, len, "void igemm_kernel<%s, %d, %d, %d, %s>(ffn_igemm_desc)", t, bm, bn, d->conv ? 1 : 0, swap);
     else {
         const int nwm = nw == 16 ? 4 : (nw == 8 ? (bn == 64 ? 4 : 2) : 2), nwn = nw / nwm;
-        snprintf(buf, len, "void igemm_glds_kernel<%s, %d, %d, %d, %s, %d, %d, %d, false>(ffn_igemm_desc)", t, bm, bn, d->conv ? 1 : 0, swap, ns, nwm, nwn);
+        snprintf(buf, len, "void igemm_glds_kernel<%s, %d, %d, %d, %s, %d, %d, %d, false, false>(ffn_igemm_desc)", t, bm, bn, d->conv ? 1 : 0, swap, ns, nwm, nwn);
     }
     return FFN_OK;
 }
@@ -761,14 +789,56 @@ static int dispatch_igemm(hipStream_t s, const ffn_igemm_desc& d) {
     if constexpr (sizeof(T) == 2) return tuned_bf16<AMODE_DENSE>(s, d);
     return dispatch_igemm_tile<T, AMODE_DENSE, true>(s, d);
 }
+// the library's private view of a split-bf16 problem: the kernels and the tile / split-K logic see the VIRTUAL contraction 3K
+static ffn_igemm_desc x3_view(const ffn_igemm_desc& d) {
+    ffn_igemm_desc v = d;
+    v.x3 = 1;
+    v.K = 3 * d.K;
+    v.flags |= FFN_IG_OUT_F32;
+    return v;
+}
+template <int BM, int BN>
+static int launch_x3_trans(hipStream_t s, const ffn_igemm_desc& d) {
+    const int ntiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+    return launch_igemm_kernel(igemm_glds_kernel<bf16, BM, BN, AMODE_DENSE, false, 2, 2, 2, false, true>, 2 * (BM + BN) * 128, s, d, ntiles, 1, 256, true);
+}
+static int dispatch_igemm_x3(hipStream_t s, const ffn_igemm_desc& d) {
+    const bool tr = d.flags & FFN_IG_OUT_TRANSPOSED;
+    if (d.conv) {
+        if (tr) return fail(FFN_EINVAL, "igemm: transposed output is only supported for dense A");
+        return tuned_bf16<AMODE_CONV3, true>(s, d);
+    }
+    if (tr) {            // V^T for the attention kernels: generic tile, fp32 transposed stores
+        int bm, bn, sk;
+        igemm_plan_for(FFN_BF16, d, &bm, &bn, &sk);
+        if (bm == 128 && bn == 128) return launch_x3_trans<128, 128>(s, d);
+        if (bm == 128) return launch_x3_trans<128, 64>(s, d);
+        return launch_x3_trans<64, 64>(s, d);
+    }
+    return tuned_bf16<AMODE_DENSE, true>(s, d);
+}
+extern "C" int ffn_split_pair(void* stream, const float* src, void* dst, long rows, int C, int ld_src) {
+    REQUIRE(src && dst && rows > 0 && C > 0 && C % 4 == 0 && ld_src >= C && ld_src % 4 == 0, "split_pair: bad arguments (C=%d, ld_src=%d)", C, ld_src);
+    REQUIRE(aligned16(src) && aligned16(dst), "split_pair: pointers must be 16-byte aligned");
+    LAUNCH(split_pair_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, (bf16*)dst, rows, C, ld_src);
+    return check_launch("split_pair");
+}
 extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
     REQUIRE(d, "igemm: null descriptor");
-    REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "igemm: bad dtype %d", dtype);
+    REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16 || dtype == FFN_BF16X3, "igemm: bad dtype %d", dtype);
     const int epc = dtype == FFN_F32 ? 4 : 8, kstage = 8 * epc;
+    const int kmul = dtype == FFN_BF16X3 ? 3 : 1;
     REQUIRE(d->A && d->W && d->out, "igemm: null A/W/out");
     REQUIRE(aligned16(d->A) && aligned16(d->W) && aligned16(d->out), "igemm: A/W/out must be 16-byte aligned");
     REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "igemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
-    REQUIRE(d->Kpad >= d->K && d->Kpad % epc == 0, "igemm: Kpad=%d (row stride of W) must be >= K=%d and a multiple of %d", d->Kpad, d->K, epc);
+    REQUIRE(d->Kpad >= kmul * d->K && d->Kpad % epc == 0, "igemm: Kpad=%d (row stride of W) must be >= K=%d and a multiple of %d", d->Kpad, kmul * d->K, epc);
+    if (dtype == FFN_BF16X3) {
+        const int plane = d->conv ? d->Cin : d->K;
+        REQUIRE(d->a_lo % 8 == 0 && d->a_lo >= plane && d->a_lo + plane <= d->lda, "igemm: split-bf16 A needs planes of %d elements: a_lo=%d, lda=%d", plane, d->a_lo, d->lda);
+        REQUIRE(d->lda % 8 == 0, "igemm: lda=%d must be a multiple of 8", d->lda);
+        REQUIRE(d->alpha == 1.0f, "igemm: split-bf16 problems take alpha = 1");
+        if (d->residual) REQUIRE(aligned16(d->residual), "igemm: fp32 residual must be 16-byte aligned");
+    }
     (void)kstage;
     REQUIRE(d->K % epc == 0, "igemm: K=%d must be a multiple of %d", d->K, epc);
     REQUIRE(d->rows_per_batch > 0, "igemm: rows_per_batch must be > 0");
@@ -796,7 +866,10 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
     if (d->ws) REQUIRE(aligned16(d->ws) && d->ws_bytes >= 0, "igemm: workspace must be 16-byte aligned");
     REQUIRE(d->splitk >= 0, "igemm: splitk must be >= 0");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return dtype == FFN_F32 ? dispatch_igemm<float>(s, *d) : dispatch_igemm<bf16>(s, *d);
+    if (dtype == FFN_BF16X3) return dispatch_igemm_x3(s, x3_view(*d));
+    ffn_igemm_desc plain = *d;
+    plain.x3 = 0;
+    return dtype == FFN_F32 ? dispatch_igemm<float>(s, plain) : dispatch_igemm<bf16>(s, plain);
 }
 
 extern "C" int ffn_igemm_tune(void* stream, int dtype, const ffn_igemm_desc* d) { return ffn_igemm(stream, dtype, d); }

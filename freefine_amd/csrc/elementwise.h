@@ -134,6 +134,25 @@ __global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ src, T
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) DT<TD>::st(dst + i, DT<TS>::ld(src + i));
 }
 
+// fp32 [rows][ld_src] (first C columns) -> the split-bf16 PAIR form the FFN_BF16X3 GEMMs read: bf16 [rows][2C], hi = bf16(x) (RNE) in
+// columns [0, C), lo = bf16(x - hi) in [C, 2C).  hi + lo carries 16-17 significant bits of x; 4 elements (16 B in, 2 x 8 B out) per thread.
+__global__ __launch_bounds__(256) void split_pair_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long rows, int C, int ld_src) {
+    const int cq = C >> 2;
+    const long n = rows * cq;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / cq;
+        const int c = (int)(i - r * cq) << 2;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(src + r * ld_src + c);
+        u32x2 hi, lo;
+        hi[0] = pack_bf16x2(x[0], x[1]);
+        hi[1] = pack_bf16x2(x[2], x[3]);
+        lo[0] = pack_bf16x2(x[0] - __uint_as_float(hi[0] << 16), x[1] - __uint_as_float(hi[0] & 0xffff0000u));
+        lo[1] = pack_bf16x2(x[2] - __uint_as_float(hi[1] << 16), x[3] - __uint_as_float(hi[1] & 0xffff0000u));
+        *reinterpret_cast<u32x2*>(dst + r * 2 * C + c) = hi;
+        *reinterpret_cast<u32x2*>(dst + r * 2 * C + C + c) = lo;
+    }
+}
+
 // image pre/post for the VAE bracket (model.py:1282-1288, 270-280)
 // uint8 HWC [B,HW,3] -> T NHWC [B,HW,CP]: v/127.5 - 1
 template <typename T>

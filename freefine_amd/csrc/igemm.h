@@ -17,6 +17,7 @@
 // LDS rows are 128 B with a 16-byte-chunk XOR swizzle (chunk ^= row & 7): conflict-free for both the
 // ds_write_b128 of the loader and the ds_read_b128 fragment reads.
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "../../include/freefine_hip.h"
 
@@ -316,8 +317,15 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // NS = LDS ring depth (NS-1 stages in flight), NWM x NWN = wave grid over the BM x BN tile (4 or 8 waves)
 // FASTK: the caller guarantees K % 64-byte-stage == 0 (dense) / Cin % stage == 0 (conv): the streaming loader below is used
-template <typename T, int BM, int BN, int AMODE, bool SWAP, int NS = 2, int NWM = 2, int NWN = 2, bool FASTK = false>
+// X3 (FFN_BF16X3, "split-bf16"): every fp32 value is carried as hi + lo (two bf16) and a product as hi*hi + hi*lo + lo*hi on the bf16
+// MFMA with fp32 accumulation.  Nothing changes in the multiplier: the GEMM simply runs over a VIRTUAL contraction of 3K --
+//   A: pair-format rows [hi(0..K) ... | lo at column a_lo ...] read as segments [A_hi | A_hi | A_lo]   (p.K holds 3K, Kr = K)
+//   W: packed [N][3K] = [W_hi | W_lo | W_hi] (conv: per tap), plain rows
+// so only the loader's K -> (tap, column) map differs.  Output / residual are fp32 (epilogue instantiated for float).
+template <typename T, int BM, int BN, int AMODE, bool SWAP, int NS = 2, int NWM = 2, int NWN = 2, bool FASTK = false, bool X3 = false>
 __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmParams p) {
+    typedef typename std::conditional<X3, float, T>::type TO;      // element type of out / residual
+    static_assert(!X3 || (sizeof(T) == 2 && !FASTK && NS == 2), "split-bf16: bf16 operands, recomputing loader");
     constexpr int EPC = DT<T>::EPC;
     constexpr int BKE = 8 * EPC;  // K elements per stage (128 bytes)
     constexpr int NW = NWM * NWN;
@@ -388,18 +396,35 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
     prep(m0, n0);
     const int He = p.Hin << p.upsample, We = p.Win << p.upsample;
 
+    const int Kr = X3 ? p.K / 3 : p.K;           // the real contraction length (dense)
+    const int pix = X3 ? p.lda : p.Cin;           // conv: elements per input pixel (pair format: hi and lo planes side by side)
     auto issue = [&](int kt, int buf) {
         const int kk = kt * BKE + csrc * EPC;
         const bool kin = kk < p.K;
         if (AMODE == AMODE_DENSE) {
+            int ka = kk;
+            if (X3) {                             // segment 0, 1: hi plane; segment 2: lo plane (a chunk never straddles: Kr % 8 == 0)
+                const int seg = (kk >= Kr) + (kk >= 2 * Kr);
+                ka = kk - seg * Kr + (seg == 2 ? p.a_lo : 0);
+            }
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 if (GA % NW != 0 && wave + NW * i >= GA) continue;
-                const char* src = (a_ok[i] && kin) ? reinterpret_cast<const char*>(Ag + a_base[i] + kk) : zero;
+                const char* src = (a_ok[i] && kin) ? reinterpret_cast<const char*>(Ag + a_base[i] + ka) : zero;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * BM * 128 + (8 * (wave + NW * i)) * 128), 16, 0, 0);
             }
         } else {
-            const int tap = kk / p.Cin, ci = kk - tap * p.Cin;
+            int tap, ci;
+            if (X3) {
+                const int c3 = 3 * p.Cin;
+                tap = kk / c3;
+                const int r = kk - tap * c3;
+                const int seg = (r >= p.Cin) + (r >= 2 * p.Cin);
+                ci = r - seg * p.Cin + (seg == 2 ? p.a_lo : 0);
+            } else {
+                tap = kk / p.Cin;
+                ci = kk - tap * p.Cin;
+            }
             const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
@@ -408,7 +433,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
                 const bool inb = a_ok[i] && kin && yy >= 0 && yy < He && xx >= 0 && xx < We;
                 yy >>= p.upsample;
                 xx >>= p.upsample;
-                const char* src = inb ? reinterpret_cast<const char*>(Ag + (a_base[i] + (long)yy * p.Win + xx) * p.Cin + ci) : zero;
+                const char* src = inb ? reinterpret_cast<const char*>(Ag + (a_base[i] + (long)yy * p.Win + xx) * pix + ci) : zero;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * BM * 128 + (8 * (wave + NW * i)) * 128), 16, 0, 0);
             }
         }
@@ -549,7 +574,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
                 compute(buf);
                 buf ^= 1;
             }
-            igemm_epilogue<T, FM, FN, SWAP>(p, acc, m0 + wm * WM, n0 + wn * WN, l15, g);
+            igemm_epilogue<TO, FM, FN, SWAP>(p, acc, m0 + wm * WM, n0 + wn * WN, l15, g);
             if (next >= ntiles) break;
             tile = next;
             m0 = (tile / ntn) * BM;
@@ -574,7 +599,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
             compute(buf);
             buf = (buf + 1 == NS) ? 0 : buf + 1;
         }
-        igemm_epilogue<T, FM, FN, SWAP>(p, acc, m0 + wm * WM, n0 + wn * WN, l15, g);
+        igemm_epilogue<TO, FM, FN, SWAP>(p, acc, m0 + wm * WM, n0 + wn * WN, l15, g);
     }
 }
 

@@ -71,7 +71,11 @@ __device__ __forceinline__ void pp_barrier() {
 #ifdef PP_TRACE
 __device__ unsigned long long pp_trace[256 * 64];   // tools/native/pp_bench.hip: 100 MHz timestamps around the low-row stores of each tile
 #endif
-template <int BM, int BN, int AMODE, bool RES, bool GEGLU, bool SPLIT = false, bool TRANS = false>
+// X3 (FFN_BF16X3, split-bf16 operands; see igemm.h): the multiplier is untouched -- the K-tile stream simply runs over the virtual
+// contraction [A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi] (p.K = 3 x the real K; per conv tap), which is a different SCALAR K
+// position per K tile (k_position) and a pixel stride of p.lda instead of Cin.  Output and residual are fp32: accumulators start at
+// bias + row bias + fp32 residual, the epilogue stores 16 bytes per lane through the same lane permutation as the split-K slabs.
+template <int BM, int BN, int AMODE, bool RES, bool GEGLU, bool SPLIT = false, bool TRANS = false, bool X3 = false>
 __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int splitk = 1) {
     typedef bf16 T;
     constexpr int HM = BM / 2;              // rows per wave (128 or 96)
@@ -85,7 +89,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     constexpr int NB1 = (FN + 1) / 2;       // B pieces requested in phase 1 (the rest in phase 2)
     // store instructions of one half-tile epilogue (every one is issued: no lane predicate around them); bf16 row-major output goes
     // out as pairs of fragments (store_rows)
-    constexpr int NST = (SPLIT || TRANS) ? FH * FN : (GEGLU ? FH * FN / 2 : FH * ((FN + 1) / 2));
+    constexpr int NST = (SPLIT || TRANS || X3) ? (GEGLU ? FH * FN / 2 : FH * FN) : (GEGLU ? FH * FN / 2 : FH * ((FN + 1) / 2));
+    constexpr int OSZ = X3 ? 4 : 2;         // bytes per output / residual element
     constexpr int OOB = (int)0x80000000;
     static_assert((BM == 256 || BM == 192) && (BN == 256 || BN == 320), "tiles built for this kernel");
     static_assert(!GEGLU || FN % 2 == 0, "GEGLU pairs hidden / gate column blocks inside a wave");
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     const int lrow = lane >> 3, csrc = (lane & 7) ^ lrow;
 
     static_assert(!SPLIT || (!RES && !GEGLU), "split-K slabs carry raw accumulators: the epilogue runs in the reduce kernel");
-    static_assert(!TRANS || (!RES && !GEGLU && !SPLIT && AMODE == AMODE_DENSE), "transposed output: dense A, bias only");
+    static_assert(!TRANS || (!RES && !GEGLU && !SPLIT && !X3 && AMODE == AMODE_DENSE), "transposed output: dense A, bias only");
     const int ntn = p.N / BN;
     const int ntm = (p.M + BM - 1) / BM;
     const int nsl = SPLIT ? splitk : 1;               // K slices per output tile (the launcher picks a divisor of K / 64)
@@ -111,16 +116,17 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     const int S = my_tiles * nk;                      // K tiles this workgroup multiplies, in stream order
 
     // ---- descriptors ----------------------------------------------------------------------------------------------------------
-    const long a_bytes = AMODE == AMODE_DENSE ? (long)p.M * p.lda * 2 : (long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * 2;
+    const int PIX = X3 ? p.lda * 2 : p.Cin * 2;        // conv: bytes per input pixel (pair format: hi and lo planes side by side)
+    const long a_bytes = AMODE == AMODE_DENSE ? (long)p.M * p.lda * 2 : (long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * PIX;
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (int)((long)p.N * p.Kpad * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
     const int nbatch = (p.M + p.rows_per_batch - 1) / p.rows_per_batch;
     const __amdgpu_buffer_rsrc_t rsrcRb =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.rowbias), 0, p.rowbias ? ((nbatch - 1) * p.ldrb + p.N) * 4 : 0, 0x00020000);
-    const long o_bytes = TRANS ? (long)((p.M + p.rows_per_batch - 1) / p.rows_per_batch) * p.N * p.ldo * 2 : (long)p.M * p.ldo * 2;
+    const long o_bytes = TRANS ? (long)((p.M + p.rows_per_batch - 1) / p.rows_per_batch) * p.N * p.ldo * 2 : (long)p.M * p.ldo * OSZ;
     const __amdgpu_buffer_rsrc_t rsrcO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)o_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, RES ? (int)((long)p.M * p.ldr * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, RES ? (int)((long)p.M * p.ldr * OSZ) : 0, 0x00020000);
 
     // ---- loader: runs one K tile ahead of the multiplier along the stream (tile, kt) ------------------------------------------
     // A pieces (8 rows x 128 B = one wave-instruction).  The rows each wave multiplies in phases 1 and 3 ("low": the first HM/2 rows
@@ -152,12 +158,26 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     // (the nine taps of a chunk back to back) and (ky, chunk, kx) -- and both run 5-13 % SLOWER (310 / 313 vs 289 us at M = 196608,
     // Cin = 320; 373 vs 339 us at 32x32 x 640): the launch is not bound by where its lines come from, and the strided walks lose more
     // (requests to lines still in flight, weight rows no longer streamed) than the L2 hits return.
-    const int cpt = AMODE == AMODE_DENSE ? 1 : p.Cin / 64;
-    const int cpt_rcp = (65536 + cpt - 1) / cpt;
+    // X3: a tap's K tiles are [cptr hi chunks (x W_hi) | the same cptr hi chunks (x W_lo) | cptr lo chunks (x W_hi)]; a dense problem
+    // is one "tap" of cptr = K / 64 chunks.  The 20-bit reciprocal is exact while kt * cpt < 2^20 (kt < 9 cpt, cpt < 341).
+    const int cptr = AMODE == AMODE_DENSE ? (X3 ? p.K / 192 : 1) : p.Cin / 64;      // real 64-element chunks per tap
+    const int cpt = X3 ? 3 * cptr : cptr;
+    const int cpt_rcp = X3 ? ((1 << 20) + cpt - 1) / cpt : (65536 + cpt - 1) / cpt;
+    const int lo_bytes = X3 ? p.a_lo * 2 : 0;
     int ka = 0, tap_ky = 0, tap_kx = 0, tap_off = 0;  // of K tile l_kt; set by k_position()
     auto k_position = [&]() {
         const int kt = l_k0 + l_kt;
-        if (AMODE == AMODE_DENSE) {
+        if constexpr (X3) {
+            const int tap = AMODE == AMODE_DENSE ? 0 : (kt * cpt_rcp) >> 20;
+            const int r = kt - tap * cpt;
+            const int seg = (r >= cptr) + (r >= 2 * cptr);
+            ka = (r - seg * cptr) * 128 + (seg == 2 ? lo_bytes : 0);
+            if (AMODE != AMODE_DENSE) {
+                tap_ky = (tap * 21846) >> 16;
+                tap_kx = tap - 3 * tap_ky;
+                tap_off = (tap_ky * p.Win + tap_kx) * PIX;
+            }
+        } else if (AMODE == AMODE_DENSE) {
             ka = kt * 128;
         } else {
             const int tap = (kt * cpt_rcp) >> 16;
@@ -182,7 +202,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
                 const int b = ma / hw, rem = ma - b * hw;
                 const int yo = rem / p.Wout, xo = rem - yo * p.Wout;
                 const int y0 = yo * p.stride - p.pad, x0 = xo * p.stride - p.pad;       // in (nearest-2x upsampled) input coordinates
-                a_off[i] = ((b * p.Hin + (y0 >> p.upsample)) * p.Win + (x0 >> p.upsample)) * (p.Cin * 2) + csrc * 16;
+                a_off[i] = ((b * p.Hin + (y0 >> p.upsample)) * p.Win + (x0 >> p.upsample)) * PIX + csrc * 16;
                 a_yx[i] = m < p.M ? ((y0 << 16) | (x0 & 0xffff)) : (int)0x80008000;       // rows past M: every tap out of the image
             }
         }
@@ -197,7 +217,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
             int toff = tap_off;
             if (p.upsample) {     // fused nearest-2x upsample: source pixel (yy >> 1, xx >> 1); the step from tap (0,0) depends on the parity of y0 / x0
                 const int dy = (tap_ky + (y0 & 1)) >> 1, dx = (tap_kx + (x0 & 1)) >> 1;
-                toff = (dy * p.Win + dx) * (p.Cin * 2);
+                toff = (dy * p.Win + dx) * PIX;
             }
             voff = inb ? voff + toff : OOB;
         }
@@ -305,11 +325,19 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         // residual: all loads of the half tile first (their registers are the half's own, dead, accumulators' worth), ONE wait, then
         // the sums -- hipcc waits vmcnt(0) at the first use of a register-destination load while LDS-DMA loads are in flight, so a
         // load-use pair per fragment row would drain the K-tile stream once per row
-        constexpr int RB = (BM == 256 && BN == 320) ? 2 : FH;      // fragment rows per batch (register budget of the largest tile)
+        constexpr int RB = X3 ? 1 : ((BM == 256 && BN == 320) ? 2 : FH);      // fragment rows per batch (register budget of the largest tile)
 #pragma unroll
         for (int ib = i0; ib < i0 + FH; ib += RB) {
-            u32x2 w[RES ? RB : 1][RES ? FN : 1];
-            if constexpr (RES) {
+            u32x2 w[(RES && !X3) ? RB : 1][(RES && !X3) ? FN : 1];
+            u32x4 w4[(RES && X3) ? RB : 1][(RES && X3) ? FN : 1];
+            if constexpr (RES && X3) {               // fp32 residual: 16 bytes per lane
+                const int voff = (l15 * p.ldr + 4 * g) * 4;
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        w4[i][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcR, voff, ((m0 + (ib + i) * 16) * p.ldr + n0 + j * 16) * 4, 0));
+            } else if constexpr (RES) {
                 const int voff = (l15 * p.ldr + 4 * g) * 2;
 #pragma unroll
                 for (int i = 0; i < RB; ++i)
@@ -323,7 +351,9 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
                     const f32x4 c = *reinterpret_cast<const f32x4*>(slot + (j * 16 + 4 * g) * 4) + *reinterpret_cast<const f32x4*>(slot + rb_off + (j * 16 + 4 * g) * 4);
-                    if constexpr (RES) {
+                    if constexpr (RES && X3) {
+                        acc[i][j] = c + __builtin_bit_cast(f32x4, w4[i - ib][j]);
+                    } else if constexpr (RES) {
                         const unsigned w0 = w[i - ib][j][0], w1 = w[i - ib][j][1];
                         acc[i][j][0] = c[0] + __uint_as_float(w0 << 16);
                         acc[i][j][1] = c[1] + __uint_as_float(w0 & 0xffff0000u);
@@ -389,6 +419,30 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
             for (int i = i0; i < i0 + FH; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(acc[i][j]));
+            return;
+        }
+        if constexpr (X3) {                           // fp32 row-major output: lane (pr, pg) stores columns 4 pg .. 4 pg + 3 of row pr, 16 bytes
+            const int voff = (pr * p.ldo + 4 * pg) * 4;
+#pragma unroll
+            for (int i = i0; i < i0 + FH; ++i) {
+                const int vo = m0 + i * 16 + pr < p.M ? voff : OOB;
+                if constexpr (GEGLU) {
+#pragma unroll
+                    for (int j = 0; j + 1 < FN; j += 2) {
+                        u32x4 w;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) w[r] = perm(__float_as_uint(acc[i][j][r] * gelu_erf_fast(acc[i][j + 1][r])));
+                        __builtin_amdgcn_raw_buffer_store_b128(w, rsrcO, vo, ((m0 + i * 16) * p.ldo + n0 / 2 + (j / 2) * 16) * 4, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        u32x4 w = __builtin_bit_cast(u32x4, acc[i][j]);
+                        w[0] = perm(w[0]); w[1] = perm(w[1]); w[2] = perm(w[2]); w[3] = perm(w[3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(w, rsrcO, vo, ((m0 + i * 16) * p.ldo + n0 + j * 16) * 4, 0);
+                    }
+                }
+            }
             return;
         }
         // bf16 row-major output.  Output fragments (16 columns = 32 B per row) are taken in PAIRS: v_permlane16_swap exchanges

@@ -77,18 +77,39 @@ def _tname(t):
     return "float" if t.dtype == torch.float32 else "bf16"
 
 
-def _igemm_name(lib, x, d):
+def _igemm_name(lib, dcode, d):
     buf = CT.create_string_buffer(160)
-    lib.ffn_igemm_kernel_name(_dt(x), CT.byref(d), buf, 160)
+    lib.ffn_igemm_kernel_name(dcode, CT.byref(d), buf, 160)
     return buf.value.decode()
 
 
 # ---------------------------------------------------------------------------------------------------------------
 # weight packing (host side, once at load time)
 # ---------------------------------------------------------------------------------------------------------------
-def pack_linear(w, dtype):
-    """[N, K] -> [N, Kpad] zero padded, contiguous, dtype."""
+def _mark_x3(t):
+    t._ffn_x3 = True          # linear() / conv3x3() recognise a split-bf16 weight by this tag and run the FFN_BF16X3 path
+    return t
+
+
+def is_x3(w):
+    return getattr(w, "_ffn_x3", False)
+
+
+def split_hi_lo(w):
+    """fp32 -> (hi, lo) bf16 with hi = bf16(w) (RNE), lo = bf16(w - hi): the operand form of the FFN_BF16X3 GEMMs"""
+    w = w.float()
+    hi = w.to(torch.bfloat16)
+    return hi, (w - hi.float()).to(torch.bfloat16)
+
+
+def pack_linear(w, dtype, x3=False):
+    """[N, K] -> [N, Kpad] zero padded, contiguous, dtype.  x3 (split-bf16, include/freefine_hip.h FFN_BF16X3): bf16 [N, 3K] =
+    [W_hi | W_lo | W_hi], the virtual contraction the kernels run against the activation's [A_hi | A_hi | A_lo]."""
     n, k = w.shape
+    if x3:
+        assert k % 8 == 0, f"split-bf16 weights need K % 8 == 0 (K={k})"
+        hi, lo = split_hi_lo(w)
+        return _mark_x3(torch.cat([hi, lo, hi], dim=1).contiguous())
     ks = kstage(dtype)
     kpad = (k + ks - 1) // ks * ks
     out = torch.zeros(n, kpad, dtype=dtype, device=w.device)
@@ -96,25 +117,42 @@ def pack_linear(w, dtype):
     return out
 
 
-def pack_conv3x3(w, dtype, cin_pad=None):
-    """[Cout, Cin, 3, 3] -> [Cout, Kpad], k = (ky*3+kx)*Cin_p + ci."""
+def pack_conv3x3(w, dtype, cin_pad=None, x3=False):
+    """[Cout, Cin, 3, 3] -> [Cout, Kpad], k = (ky*3+kx)*Cin_p + ci  (x3: k' = ((ky*3+kx)*3 + seg)*Cin_p + ci, seg = hi, lo, hi)."""
     cout, cin = w.shape[:2]
     cp = cin_pad or cin
     w2 = torch.zeros(cout, 3, 3, cp, dtype=torch.float32, device=w.device)
     w2[..., :cin] = w.permute(0, 2, 3, 1).float()
+    if x3:
+        assert cp % 8 == 0, f"split-bf16 conv weights need Cin % 8 == 0 (Cin={cp})"
+        hi, lo = split_hi_lo(w2.reshape(cout, 9, cp))
+        return _mark_x3(torch.cat([hi, lo, hi], dim=2).reshape(cout, 27 * cp).contiguous())
     return pack_linear(w2.reshape(cout, 9 * cp), dtype)
 
 
-def pack_geglu(w, b, dtype):
+def pack_geglu(w, b, dtype, x3=False):
     """GEGLU proj [2F, K] (+bias [2F]): interleave 16-row blocks hidden/gate so one lane holds both halves."""
     f2, k = w.shape
     f = f2 // 2
     assert f % 16 == 0
     idx = torch.arange(f, device=w.device).reshape(f // 16, 16)
     order = torch.stack([idx, idx + f], dim=1).reshape(-1)  # [h0..h15, g0..g15, h16.., ...]
-    wp = pack_linear(w[order], dtype)
+    wp = pack_linear(w[order], dtype, x3)
     bp = None if b is None else b[order].float().contiguous()
     return wp, bp
+
+
+def split_pair(x, K=None):
+    """fp32 [..., ld] (first K columns) -> bf16 PAIR rows [..., 2K] = [hi | lo] (ffn_split_pair): the A operand of an FFN_BF16X3 GEMM"""
+    lib = L.load()
+    assert x.dtype == torch.float32 and x.stride(-1) == 1
+    K = K if K is not None else x.shape[-1]
+    rows = x.numel() // x.shape[-1]
+    ld = x.stride(-2) if x.ndim > 1 else x.shape[-1]
+    out = torch.empty(*x.shape[:-1], 2 * K, dtype=torch.bfloat16, device=x.device)
+    L.check(_timed("split_pair_kernel", 0.0, 8.0 * rows * K, lambda: lib.ffn_split_pair(_stream(), x.data_ptr(), out.data_ptr(), rows, K, ld)),
+            "ffn_split_pair")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -140,10 +178,14 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
     M = x.numel() // x.shape[-1]
     N = w.shape[0]
     d = L.IgemmDesc()
-    d.A, d.W = x.data_ptr(), w.data_ptr()
+    x3 = is_x3(w)
+    xa = split_pair(x, K) if x3 else x              # split-bf16: fp32 activations -> [hi | lo] bf16 rows; results / residual stay fp32
+    dcode = L.FFN_BF16X3 if x3 else _dt(x)
+    d.A, d.W = xa.data_ptr(), w.data_ptr()
     d.bias, d.rowbias, d.residual = _p(bias), _p(rowbias), _p(residual)
     d.M, d.N, d.K, d.Kpad = M, N, K, w.stride(0)    # Kpad = row stride of W (an activation view can serve as W)
-    d.lda = x.stride(-2) if x.ndim > 1 else x.shape[-1]
+    d.lda = xa.stride(-2) if xa.ndim > 1 else xa.shape[-1]
+    d.a_lo = K if x3 else 0
     d.rows_per_batch = rows_per_batch or M
     d.ldrb = rowbias.stride(0) if rowbias is not None else 0
     flags = 0
@@ -173,11 +215,11 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
     d.flags, d.alpha, d.conv = flags, alpha, 0
     d.splitk, d.ws, d.ws_bytes = splitk, _workspace(x.device).data_ptr(), WS_BYTES
     if _PROF is None:
-        L.check(lib.ffn_igemm(_stream(), _dt(x), CT.byref(d)), "ffn_igemm")
+        L.check(lib.ffn_igemm(_stream(), dcode, CT.byref(d)), "ffn_igemm")
     else:
         esz = x.element_size()
-        L.check(_timed(_igemm_name(lib, x, d), 2.0 * M * N * K, esz * (M * K + N * K + M * n_out),
-                       lambda: lib.ffn_igemm(_stream(), _dt(x), CT.byref(d))), "ffn_igemm")
+        L.check(_timed(_igemm_name(lib, dcode, d), 2.0 * M * N * K, esz * (M * K + N * K + M * n_out),
+                       lambda: lib.ffn_igemm(_stream(), dcode, CT.byref(d))), "ffn_igemm")
     return out
 
 
@@ -191,10 +233,14 @@ def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, ou
         Wout = (We + 2 * pad - 3) // stride + 1
     N = w.shape[0]
     d = L.IgemmDesc()
-    d.A, d.W = x.data_ptr(), w.data_ptr()
+    x3 = is_x3(w)
+    xa = split_pair(x, Cin) if x3 else x            # split-bf16: every pixel becomes [hi(Cin) | lo(Cin)]
+    dcode = L.FFN_BF16X3 if x3 else _dt(x)
+    d.A, d.W = xa.data_ptr(), w.data_ptr()
     d.bias, d.rowbias, d.residual = _p(bias), _p(rowbias), _p(residual)
     d.M, d.N, d.K, d.Kpad = B * Hout * Wout, N, 9 * Cin, w.shape[1]
-    d.lda = Cin
+    d.lda = 2 * Cin if x3 else Cin
+    d.a_lo = Cin if x3 else 0
     d.rows_per_batch = Hout * Wout
     d.ldrb = (rowbias_ld or rowbias.stride(0)) if rowbias is not None else 0
     if out is None:
@@ -206,11 +252,11 @@ def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, ou
     d.flags, d.alpha, d.conv = (L.IG_OUT_F32 if out_f32 else 0), 1.0, 1
     d.splitk, d.ws, d.ws_bytes = splitk, _workspace(x.device).data_ptr(), WS_BYTES
     if _PROF is None:
-        L.check(lib.ffn_igemm(_stream(), _dt(x), CT.byref(d)), "ffn_igemm(conv)")
+        L.check(lib.ffn_igemm(_stream(), dcode, CT.byref(d)), "ffn_igemm(conv)")
     else:
         esz = x.element_size()
-        L.check(_timed(_igemm_name(lib, x, d), 2.0 * d.M * N * d.K, esz * (x.numel() + N * d.K + d.M * N),
-                       lambda: lib.ffn_igemm(_stream(), _dt(x), CT.byref(d))), "ffn_igemm(conv)")
+        L.check(_timed(_igemm_name(lib, dcode, d), 2.0 * d.M * N * d.K, esz * (x.numel() + N * d.K + d.M * N),
+                       lambda: lib.ffn_igemm(_stream(), dcode, CT.byref(d))), "ffn_igemm(conv)")
     return out
 
 

@@ -61,11 +61,13 @@ class FreeFinePipeline:
     # construction (freefine_batch_infer_2d.py:148-157)
     # ------------------------------------------------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, path, torch_dtype=torch.float32, device="cuda:0", seed=0, broadcast="auto", **kw):
+    def from_pretrained(cls, path, torch_dtype=torch.float32, device="cuda:0", seed=0, broadcast="auto", x3=False, **kw):
         """`path` is either a HF-layout Stable-Diffusion folder (unet/, vae/ safetensors + config.json; tokenizer/,
         text_encoder/ loaded through transformers when present) or "synthetic:<unet preset>[:<vae preset>]" for
         seeded random weights of that architecture (no checkpoints exist in the build environment).
-        torch_dtype float32 -> exact-fp32 parity mode; float16/bfloat16 -> bf16 MFMA fast mode.
+        torch_dtype float32 -> exact-fp32 parity mode; float16/bfloat16 -> bf16 MFMA fast mode; float32 with x3=True -> the
+        split-bf16 mode (fp32 activations, every UNet GEMM on three bf16 MFMAs per product term: fp32-level results at several
+        times the fp32-MFMA rate; the VAE bracket stays exact fp32).
         In a torch.distributed job (`broadcast="auto"`: whenever a process group with more than one rank is initialised) only
         rank 0 reads / generates the UNet and VAE weights; the other ranks receive them over RCCL straight into device memory
         (freefine_amd.dist.broadcast_state; bf16 payload for the matrices in fast mode) -- the reference has every rank read
@@ -114,14 +116,14 @@ class FreeFinePipeline:
             mdt = torch.float32 if dtype == torch.float32 else torch.bfloat16
             ust = FD.broadcast_state(ust, unet_param_shapes(ucfg), device, matrix_dtype=mdt)
             vst = FD.broadcast_state(vst, vae_param_shapes(vcfg), device, matrix_dtype=mdt)
-        return cls.from_state(ucfg, ust, vcfg, vst, tok, enc, sched, dtype, device)
+        return cls.from_state(ucfg, ust, vcfg, vst, tok, enc, sched, dtype, device, x3=x3)
 
     @classmethod
-    def from_state(cls, ucfg, ustate, vcfg, vstate, tokenizer, text_encoder, scheduler=None, dtype=torch.float32, device="cuda:0"):
+    def from_state(cls, ucfg, ustate, vcfg, vstate, tokenizer, text_encoder, scheduler=None, dtype=torch.float32, device="cuda:0", x3=False):
         ustate, vstate = normalize_state_dict(ustate), normalize_state_dict(vstate)      # hub checkpoints: legacy VAE attention names
         validate_state_dict(ustate, unet_param_shapes(ucfg), "unet")
         validate_state_dict(vstate, vae_param_shapes(vcfg), "vae")
-        unet = HipUNet(ucfg, ustate, dtype=dtype, device=device)
+        unet = HipUNet(ucfg, ustate, dtype=dtype, device=device, x3=x3)
         vae = HipVAE(vcfg, vstate, dtype=dtype, device=device)
         return cls(unet, vae, tokenizer, text_encoder, scheduler or DDIMScheduler(), device)
 

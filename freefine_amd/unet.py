@@ -26,7 +26,12 @@ class _Res:
 
 
 class HipUNet:
-    def __init__(self, cfg: UNetConfig, state, dtype=torch.bfloat16, device="cuda:0"):
+    def __init__(self, cfg: UNetConfig, state, dtype=torch.bfloat16, device="cuda:0", x3=False):
+        """dtype float32 = exact-fp32 parity mode, bfloat16 = fast mode.  x3 (with dtype float32): the split-bf16 mode -- activations,
+        norms, softmax and the residual stream stay fp32 exactly as in parity mode, every Linear / conv runs as an FFN_BF16X3 GEMM
+        (hi/lo bf16 operands, three bf16 MFMAs per product term, fp32 accumulation; include/freefine_hip.h)."""
+        assert not x3 or dtype == torch.float32, "split-bf16 mode keeps fp32 activations"
+        self.x3 = bool(x3)
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
         self.in_channels = cfg.in_channels
         self.hook, self.controller = "edit", None
@@ -48,11 +53,11 @@ class HipUNet:
         w = st[name + ".weight"].to(self.device)
         if w.ndim == 4:
             w = w.reshape(w.shape[0], w.shape[1])
-        return ops.pack_linear(w.float(), self.dtype), (self._f32(st[name + ".bias"]) if bias else None), w.shape[1]
+        return ops.pack_linear(w.float(), self.dtype, self.x3), (self._f32(st[name + ".bias"]) if bias else None), w.shape[1]
 
     def _conv(self, st, name, cin_pad=None):
         w = st[name + ".weight"].to(self.device)
-        return ops.pack_conv3x3(w.float(), self.dtype, cin_pad), self._f32(st[name + ".bias"]), (cin_pad or w.shape[1])
+        return ops.pack_conv3x3(w.float(), self.dtype, cin_pad, self.x3), self._f32(st[name + ".bias"]), (cin_pad or w.shape[1])
 
     def _resnet(self, st, p, temb_list):
         r = _Res()
@@ -76,14 +81,14 @@ class HipUNet:
         t.ln = [(self._f32(st[f"{b}.norm{i}.weight"]), self._f32(st[f"{b}.norm{i}.bias"])) for i in (1, 2, 3)]
         wq, wk = st[f"{b}.attn1.to_q.weight"].float(), st[f"{b}.attn1.to_k.weight"].float()
         t.C = wq.shape[0]
-        t.w_qk1 = ops.pack_linear(torch.cat([wq, wk], 0).to(self.device), self.dtype)          # self-attn Q|K in one GEMM
-        t.w_v1 = ops.pack_linear(st[f"{b}.attn1.to_v.weight"].float().to(self.device), self.dtype)
+        t.w_qk1 = ops.pack_linear(torch.cat([wq, wk], 0).to(self.device), self.dtype, self.x3)          # self-attn Q|K in one GEMM
+        t.w_v1 = ops.pack_linear(st[f"{b}.attn1.to_v.weight"].float().to(self.device), self.dtype, self.x3)
         t.o1 = self._lin(st, f"{b}.attn1.to_out.0")
-        t.w_q2 = ops.pack_linear(st[f"{b}.attn2.to_q.weight"].float().to(self.device), self.dtype)
-        t.w_k2 = ops.pack_linear(st[f"{b}.attn2.to_k.weight"].float().to(self.device), self.dtype)
-        t.w_v2 = ops.pack_linear(st[f"{b}.attn2.to_v.weight"].float().to(self.device), self.dtype)
+        t.w_q2 = ops.pack_linear(st[f"{b}.attn2.to_q.weight"].float().to(self.device), self.dtype, self.x3)
+        t.w_k2 = ops.pack_linear(st[f"{b}.attn2.to_k.weight"].float().to(self.device), self.dtype, self.x3)
+        t.w_v2 = ops.pack_linear(st[f"{b}.attn2.to_v.weight"].float().to(self.device), self.dtype, self.x3)
         t.o2 = self._lin(st, f"{b}.attn2.to_out.0")
-        t.ff1 = ops.pack_geglu(st[f"{b}.ff.net.0.proj.weight"].float().to(self.device), st[f"{b}.ff.net.0.proj.bias"].float().to(self.device), self.dtype)
+        t.ff1 = ops.pack_geglu(st[f"{b}.ff.net.0.proj.weight"].float().to(self.device), st[f"{b}.ff.net.0.proj.bias"].float().to(self.device), self.dtype, self.x3)
         t.ff2 = self._lin(st, f"{b}.ff.net.2")
         return t
 
@@ -91,7 +96,7 @@ class HipUNet:
         cfg = self.cfg
         ch = cfg.block_out_channels
         n = len(ch)
-        e = ops.epc(self.dtype)
+        e = 8 if self.x3 else ops.epc(self.dtype)          # split-bf16: planes of whole 16-byte bf16 chunks
         self.cin_pad = (cfg.in_channels + e - 1) // e * e
         self.conv_in = self._conv(st, "conv_in", self.cin_pad)
         self.te1 = self._lin(st, "time_embedding.linear_1")
@@ -123,7 +128,7 @@ class HipUNet:
         self.conv_out = self._conv(st, "conv_out")
         # conv_out has out_channels (4) outputs: fine for the kernel (N % 4 == 0)
         wcat = torch.cat([w for w, _ in temb_list], 0).to(self.device)
-        self.temb_w = ops.pack_linear(wcat, self.dtype)
+        self.temb_w = ops.pack_linear(wcat, self.dtype, self.x3)
         self.temb_b = torch.cat([b for _, b in temb_list], 0).float().to(self.device).contiguous()
         self.transformers = [t for blk in self.down if blk.attn for t in blk.attn] + self.mid.attn + \
                             [t for blk in self.up if blk.attn for t in blk.attn]

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-enum { FFN_F32 = 0, FFN_BF16 = 1 };
+enum { FFN_F32 = 0, FFN_BF16 = 1, FFN_BF16X3 = 2 /* ffn_igemm only: split-bf16 operands, fp32 results (see ffn_igemm) */ };
 enum { FFN_OK = 0, FFN_EINVAL = -22, FFN_ENOSYS = -38, FFN_EHIP = -5 };
 
 int ffn_version(void);
@@ -64,8 +64,20 @@ typedef struct ffn_igemm_desc {
     int splitk;       /* 0 = let the library choose (needs ws), 1 = never split, k = force k K-slices */
     void* ws;         /* optional fp32 scratch for split-K partial slabs (>= splitk*M*N*4 bytes) or NULL */
     long ws_bytes;
+    int a_lo;         /* FFN_BF16X3: column (conv: channel) offset of the lo plane inside a row (pixel) of A; else ignored */
+    int x3;           /* set by the library from `dtype` (callers leave it 0) */
 } ffn_igemm_desc;
 int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
+/* FFN_BF16X3 ("split-bf16", the fast mode that keeps fp32-level results): every fp32 operand value v is carried as hi = bf16(v) and
+ * lo = bf16(v - hi) (16-17 significant bits together) and a product a*w is evaluated as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the bf16
+ * MFMA with fp32 accumulation -- 3 MFMAs per product term (ceiling 2.5 PFLOP/s / 3 = 833 TFLOP/s against 157 TFLOP/s of the fp32
+ * MFMA), dropped term a_lo*w_lo ~ 2^-18.  Operand formats:
+ *   A    bf16 PAIR rows: hi plane at columns [0, K), lo plane at [a_lo, a_lo + K) of the same row (lda = row stride in bf16
+ *        elements; conv: per input pixel, planes of Cin channels, lda = elements per pixel) -- ffn_split_pair writes it from fp32;
+ *   W    bf16 [N][Kpad], Kpad >= 3K: [W_hi | W_lo | W_hi] (conv: that triple per tap, k' = (tap*3 + seg)*Cin + ci);
+ *   out, residual   fp32 (FFN_IG_OUT_F32 is implied); bias / rowbias fp32 as always; GEGLU, SILU, transposed output, split-K as in bf16.
+ * K in the descriptor is the REAL contraction length (dense K, conv 9*Cin). */
+int ffn_split_pair(void* stream, const float* src, void* dst, long rows, int C, int ld_src);
 /* Kernel families behind ffn_igemm (freefine_amd/csrc): igemm_pp_kernel (igemm_p8.h; bf16 -- 256- or 192-row "ping-pong" tiles with
  * LDS-DMA operands in flight across barriers, the default wherever N is a multiple of 256 or 320 and K a multiple of 64),
  * igemm_glds_kernel / igemm_halo_kernel (igemm.h; every other bf16 shape and all of f32).

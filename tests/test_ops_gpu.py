@@ -713,3 +713,159 @@ def test_ragged_m_tail_rows_are_not_written(gpu):
                 assert (big[M:] == 7.0).all(), (cfg, N, geglu, with_res)
     finally:
         lib.ffn_igemm_force_config(-1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# FFN_BF16X3 ("split-bf16"): fp32 activations carried as hi + lo bf16, a product = hi*hi + hi*lo + lo*hi on the bf16 MFMA with
+# fp32 accumulation.  Expected deviation from the fp64 statement: ~2^-17 per product term, averaged over K -> a few 1e-6 of the
+# output scale; the gate is 2e-5 (the f32 gate), i.e. two orders below what 1e-3 latent parity needs and three below bf16 (1.5e-2).
+# ---------------------------------------------------------------------------------------------------------------------
+X3_TOL = 2e-5
+
+
+def test_x3_split_pair(gpu):
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(37, 328, generator=g) * torch.logspace(-3, 3, 328)).to(gpu)
+    p = ops.split_pair(x, 320)
+    assert p.shape == (37, 640) and p.dtype == torch.bfloat16
+    hi, lo = p[:, :320].float(), p[:, 320:].float()
+    assert torch.equal(hi, x[:, :320].to(torch.bfloat16).float())
+    assert torch.equal(lo, (x[:, :320] - hi).to(torch.bfloat16).float())
+    assert ((hi + lo - x[:, :320]).abs() <= x[:, :320].abs() * 2.0 ** -16).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 320, 320), (4096, 1280, 320), (77 * 4, 640, 1024), (4, 1280, 320), (1000, 4, 320), (16384, 320, 1280),
+                                    (130, 200, 72), (196608 // 8, 640, 640), (2500, 1280, 5120)])
+def test_x3_linear(gpu, M, N, K):
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    dt = torch.float32
+    x = rnd((M, K), dt, gpu, g)
+    w = rnd((N, K), dt, gpu, g, K ** -0.5)
+    b = torch.randn(N, generator=g).to(gpu)
+    res = rnd((M, N), dt, gpu, g)
+    wp = ops.pack_linear(w, dt, x3=True)
+    assert ops.is_x3(wp) and wp.shape == (N, 3 * K) and wp.dtype == torch.bfloat16
+    ref = x.double() @ w.double().t() + b.double()
+    out = ops.linear(x, wp, b, K=K)
+    assert out.dtype == torch.float32
+    e0 = relerr(out, ref)
+    e1 = relerr(ops.linear(x, wp, b, K=K, residual=res), ref + res.double())
+    e2 = relerr(ops.linear(x, wp, b, K=K, silu=True), F.silu(ref))
+    print(f"x3 linear M={M} N={N} K={K}: {e0:.2e} / residual {e1:.2e} / silu {e2:.2e}")
+    assert max(e0, e1, e2) < X3_TOL
+
+
+def test_x3_geglu_rowbias_transposed_splitk(gpu):
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(3)
+    dt = torch.float32
+    B, S, K, Fh = 2, 1024, 320, 1280
+    x = rnd((B, S, K), dt, gpu, g)
+    w = rnd((2 * Fh, K), dt, gpu, g, K ** -0.5)
+    b = torch.randn(2 * Fh, generator=g).to(gpu)
+    wp, bp = ops.pack_geglu(w, b, dt, x3=True)
+    out = ops.linear(x, wp, bp, geglu=True)
+    y = x.double() @ w.double().t() + b.double()
+    ref = y[..., :Fh] * F.gelu(y[..., Fh:])
+    assert out.shape == (B, S, Fh) and out.dtype == torch.float32
+    print(f"x3 geglu: {relerr(out, ref):.2e}")
+    assert relerr(out, ref) < X3_TOL
+    w2 = rnd((640, K), dt, gpu, g, K ** -0.5)
+    rb = torch.randn(B, 640, generator=g).to(gpu)
+    out = ops.linear(x, ops.pack_linear(w2, dt, x3=True), None, rowbias=rb, rows_per_batch=S)
+    assert relerr(out, x.double() @ w2.double().t() + rb.double()[:, None, :]) < X3_TOL
+    for S2 in (256, 77, 400):        # V^T: fp32 transposed output
+        x2 = rnd((3, S2, K), dt, gpu, g)
+        ld = (S2 + 7) // 8 * 8
+        out = ops.linear(x2, ops.pack_linear(w2, dt, x3=True), None, rows_per_batch=S2, transposed_ld=ld)
+        assert out.shape == (3, 640, ld) and relerr(out[:, :, :S2], (x2.double() @ w2.double().t()).transpose(1, 2)) < X3_TOL
+    Mk, Kk, Nk = 600, 4096, 512
+    a = rnd((Mk, Kk), dt, gpu, g)
+    wl = rnd((Nk, Kk), dt, gpu, g, Kk ** -0.5)
+    for sk in (0, 1, 4, 8):
+        out = ops.linear(a, ops.pack_linear(wl, dt, x3=True), b[:Nk], splitk=sk, residual=a[:, :Nk].contiguous())
+        assert relerr(out, a.double() @ wl.double().t() + b[:Nk].double() + a[:, :Nk].double()) < X3_TOL, sk
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, H=16, W=16, Cin=64, Cout=96, stride=1, pad=1, up=False),
+    dict(B=2, H=16, W=16, Cin=64, Cout=64, stride=2, pad=1, up=False),
+    dict(B=1, H=8, W=8, Cin=128, Cout=64, stride=1, pad=1, up=True),
+    dict(B=4, H=8, W=8, Cin=320, Cout=4, stride=1, pad=1, up=False),
+    dict(B=2, H=12, W=20, Cin=8, Cout=320, stride=1, pad=1, up=False),
+    dict(B=3, H=32, W=32, Cin=128, Cout=320, stride=1, pad=1, up=False),       # ping-pong tile shapes from here on
+    dict(B=2, H=16, W=16, Cin=128, Cout=320, stride=1, pad=1, up=True),
+    dict(B=2, H=32, W=32, Cin=64, Cout=320, stride=2, pad=1, up=False),
+    dict(B=5, H=16, W=16, Cin=192, Cout=640, stride=1, pad=1, up=False),
+    dict(B=4, H=64, W=64, Cin=320, Cout=320, stride=1, pad=1, up=False),
+    dict(B=3, H=8, W=8, Cin=2560, Cout=1280, stride=1, pad=1, up=False),       # split-K at the coarse level, Cin = concat width
+])
+def test_x3_conv3x3(gpu, cfg):
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(11)
+    dt = torch.float32
+    B, H, W, Cin, Cout = cfg["B"], cfg["H"], cfg["W"], cfg["Cin"], cfg["Cout"]
+    x = rnd((B, Cin, H, W), dt, gpu, g)
+    w = rnd((Cout, Cin, 3, 3), dt, gpu, g, (9 * Cin) ** -0.5)
+    b = torch.randn(Cout, generator=g).to(gpu)
+    xin = x.double()
+    if cfg["up"]:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w.double(), b.double(), stride=cfg["stride"], padding=1)
+    Ho, Wo = ref.shape[-2:]
+    rb = torch.randn(B, Cout, generator=g).to(gpu)
+    res = rnd((B, Ho * Wo, Cout), dt, gpu, g)
+    x_nhwc = x.permute(0, 2, 3, 1).reshape(B, H * W, Cin).contiguous()
+    wp = ops.pack_conv3x3(w, dt, x3=True)
+    assert wp.shape == (Cout, 27 * Cin)
+    ref_nhwc = ref.permute(0, 2, 3, 1).reshape(B, Ho * Wo, Cout)
+    out = ops.conv3x3(x_nhwc, wp, b, B, H, W, Cin, stride=cfg["stride"], pad=1, upsample=cfg["up"], Hout=Ho, Wout=Wo)
+    e0 = relerr(out, ref_nhwc)
+    out = ops.conv3x3(x_nhwc, wp, b, B, H, W, Cin, stride=cfg["stride"], pad=1, upsample=cfg["up"], Hout=Ho, Wout=Wo, rowbias=rb, residual=res)
+    e1 = relerr(out, ref_nhwc + rb.double()[:, None] + res.double())
+    print(f"x3 conv {cfg}: {e0:.2e} / rowbias+residual {e1:.2e}")
+    assert max(e0, e1) < X3_TOL
+
+
+def test_x3_every_configuration_and_determinism(gpu):
+    """every split-bf16 configuration forced in turn (generic 64x64 / 128x64 / 128x128 tiles and the four ping-pong tiles, unsplit and
+    split-K), ragged M, GEGLU, residual; bit-repeatability of the pipelined kernel in this mode."""
+    from freefine_amd import _lib as L
+    from freefine_amd import ops
+    lib = L.load()
+    dt = torch.float32
+    g = torch.Generator().manual_seed(5)
+    try:
+        for cfg in range(lib.ffn_igemm_num_configs()):
+            lib.ffn_igemm_force_config(cfg)
+            for (M, N, K) in [(16384 + 72, 320, 320), (6000, 640, 640), (300, 328, 136)]:
+                x, w = rnd((M, K), dt, gpu, g), rnd((N, K), dt, gpu, g, K ** -0.5)
+                b, r = rnd((N,), dt, gpu, g), rnd((M, N), dt, gpu, g)
+                big = torch.full((M + 300, N), 7.0, dtype=dt, device=gpu)
+                out = ops.linear(x, ops.pack_linear(w, dt, x3=True), b, K=K, residual=r, out=big[:M])
+                assert relerr(out, x.double() @ w.double().t() + b.double() + r.double()) < X3_TOL, (cfg, M, N, K)
+                assert (big[M:] == 7.0).all(), (cfg, M, N, K)
+            M, K, Fh = 16384 + 40, 320, 640
+            x, w, b = rnd((M, K), dt, gpu, g), rnd((2 * Fh, K), dt, gpu, g, K ** -0.5), rnd((2 * Fh,), dt, gpu, g)
+            wp, bp = ops.pack_geglu(w, b, dt, x3=True)
+            y = x.double() @ w.double().t() + b.double()
+            assert relerr(ops.linear(x, wp, bp, K=K, geglu=True), y[:, :Fh] * F.gelu(y[:, Fh:])) < X3_TOL, (cfg, "geglu")
+            B, H, Cin, Cout = 3, 16, 256, 320
+            x, w = rnd((B, H * H, Cin), dt, gpu, g), rnd((Cout, Cin, 3, 3), dt, gpu, g, (9 * Cin) ** -0.5)
+            b, rb, r = rnd((Cout,), dt, gpu, g), rnd((B, Cout), dt, gpu, g), rnd((B, H * H, Cout), dt, gpu, g)
+            xr = x.double().reshape(B, H, H, Cin).permute(0, 3, 1, 2)
+            ref = F.conv2d(xr, w.double(), b.double(), padding=1) + rb.double()[:, :, None, None]
+            ref = ref.permute(0, 2, 3, 1).reshape(B, H * H, Cout) + r.double()
+            for sk in (0, 12):
+                out = ops.conv3x3(x, ops.pack_conv3x3(w, dt, x3=True), b, B, H, H, Cin, rowbias=rb, residual=r, splitk=sk)
+                assert relerr(out, ref) < X3_TOL, (cfg, "conv", sk)
+    finally:
+        lib.ffn_igemm_force_config(-1)
+    B, H, Cin, Cout = 12, 64, 320, 320
+    x, w = rnd((B, H * H, Cin), dt, gpu, g), ops.pack_conv3x3(rnd((Cout, Cin, 3, 3), dt, gpu, g, (9 * Cin) ** -0.5), dt, x3=True)
+    b, r = rnd((Cout,), dt, gpu, g), rnd((B, H * H, Cout), dt, gpu, g)
+    ref = ops.conv3x3(x, w, b, B, H, H, Cin, residual=r).clone()
+    for _ in range(4):
+        assert torch.equal(ops.conv3x3(x, w, b, B, H, H, Cin, residual=r), ref)

@@ -17,7 +17,7 @@ torch.set_grad_enabled(False)
 TOL = 1e-3
 
 
-def make_pipe(gpu, unet_name, hook, dtype=torch.float32, graph=False, seed=0, ustate=None):
+def make_pipe(gpu, unet_name, hook, dtype=torch.float32, graph=False, seed=0, ustate=None, x3=False):
     from freefine_amd.attention import (Attention_Modulator, register_attention_control, register_attention_control_4bggen,
                                         register_attention_control_compose)
     from freefine_amd.config import UNetConfig, VAEConfig
@@ -29,7 +29,7 @@ def make_pipe(gpu, unet_name, hook, dtype=torch.float32, graph=False, seed=0, us
     ust = ustate if ustate is not None else sd_unet.init_unet(ocfg, seed=seed).state_dict()
     vst = sd_vae.init_vae(sd_vae.vae_config("tiny"), seed=seed + 1).state_dict()
     model = FreeFinePipeline.from_state(UNetConfig.preset(unet_name), ust, VAEConfig.preset("tiny"), vst, ByteTokenizer(),
-                                        SyntheticTextEncoder(ocfg.cross_attention_dim), None, dtype, gpu)
+                                        SyntheticTextEncoder(ocfg.cross_attention_dim), None, dtype, gpu, x3=x3)
     model.scheduler = DDIMScheduler.from_config(model.scheduler.config)
     controller = Attention_Modulator(start_layer=10)
     model.controller = controller
@@ -263,14 +263,48 @@ def test_full_size_edit_loop_vs_oracle(gpu):
     opipe = OraclePipeline(ounet, sd_vae.init_vae(sd_vae.vae_config("tiny"), seed=1),
                            make_text_embed(ByteTokenizer(), SyntheticTextEncoder(cfg.cross_attention_dim)))
     o_img, _, o_traj = opipe.freefine_generation(ori_img, ori, coarse, tgt, "a photo of a cup", 7.5, 1.0, seed=42, **kw)
-    for graph in (False, True):
-        model = make_pipe(gpu, "sd21-base", "edit", graph=graph, ustate=ounet.state_dict())
+    for graph, x3 in ((False, False), (True, False), (True, True)):
+        model = make_pipe(gpu, "sd21-base", "edit", graph=graph, ustate=ounet.state_dict(), x3=x3)
         img = model.FreeFine_generation(ori_img, ori, coarse, tgt, "a photo of a cup", 7.5, 1.0, verbose=True, seed=42,
                                         return_intermediates=True, **kw)
         dev = traj_dev(model.last_intermediates, [t.numpy() for t in o_traj])
-        print(f"full-size 2+2-step edit, fp32, graph={graph}: absolute latent L-inf vs oracle {dev:.2e}; image max |diff| "
+        print(f"full-size 2+2-step edit, {'split-bf16' if x3 else 'fp32'}, graph={graph}: absolute latent L-inf vs oracle {dev:.2e}; image max |diff| "
               f"{np.abs(img.astype(int) - o_img.astype(int)).max()}")
         assert dev < TOL
         assert np.abs(img.astype(int) - o_img.astype(int)).max() <= 1
         del model
         torch.cuda.empty_cache()
+
+
+def test_split_bf16_mode_meets_parity_on_whole_loops(gpu):
+    """the split-bf16 mode (FFN_BF16X3 GEMMs, fp32 activations) through WHOLE loops against the REFERENCE's golden trajectories:
+    the same 1e-3 absolute latent gate as the fp32 parity mode (edit tca / mmsa, background generation, composition)."""
+    g = np.load(os.path.join(GOLD, "g5_loops.npz"))
+    ori_img, coarse, img2 = synth_images()
+    ori, tgt, *_ = mask_inputs()
+    for name, unet_name, kw in edit_cases():
+        if name not in ("edit_tca_draw", "edit_tca_auto", "edit_mmsa"):
+            continue
+        kw = dict(kw)
+        text, gs, eta = kw.pop("guidance_text"), kw.pop("guidance_scale"), kw.pop("eta")
+        model = make_pipe(gpu, unet_name, "edit", graph=True, x3=True)
+        img = model.FreeFine_generation(ori_img, ori, coarse, tgt, text, gs, eta, verbose=True, seed=42, return_intermediates=True, **kw)
+        dev = traj_dev(model.last_intermediates, g[f"{name}_traj"])
+        print(f"split-bf16 {name}: latent L-inf vs reference golden {dev:.2e}")
+        assert dev < TOL, name
+        assert np.abs(img[::4, ::4].astype(int) - g[f"{name}_img"].astype(int)).max() <= 1, name
+    name, kw = BG_CASES[0]
+    model = make_pipe(gpu, "tiny", "bggen", x3=True)
+    model.FreeFine_background_generation(ori_img, model.dilate_mask(ori // 255, 30), "empty scene", 3.5, 1.0, verbose=True, seed=7,
+                                         return_intermediates=True, **kw)
+    dev = traj_dev(model.last_intermediates, g[f"{name}_traj"])
+    print(f"split-bf16 {name}: latent L-inf vs reference golden {dev:.2e}")
+    assert dev < TOL
+    oris, tgts = compose_masks()
+    name, kw = CMP_CASES[0]
+    model = make_pipe(gpu, "tiny", "compose", x3=True)
+    model.FreeFine_cross_image_composition([ori_img, img2], oris, tgts, coarse, ["a cup", "a dog"], 7.5, 1.0, end_step=8, num_step=10,
+                                           start_step=6, verbose=True, seed=11, dil_factor=9, end_scale=0.5, return_intermediates=True, **kw)
+    dev = traj_dev(model.last_intermediates, g[f"{name}_traj"])
+    print(f"split-bf16 {name}: latent L-inf vs reference golden {dev:.2e}")
+    assert dev < TOL

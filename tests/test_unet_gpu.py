@@ -11,13 +11,13 @@ pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
 
-def build(name, dtype, gpu, seed=0):
+def build(name, dtype, gpu, seed=0, x3=False):
     from freefine_amd.config import UNetConfig
     from freefine_amd.unet import HipUNet
     from oracle import sd_unet
     ocfg = sd_unet.unet_config(name)
     onet = sd_unet.init_unet(ocfg, seed=seed)
-    hnet = HipUNet(UNetConfig.preset(name), onet.state_dict(), dtype=dtype, device=gpu)
+    hnet = HipUNet(UNetConfig.preset(name), onet.state_dict(), dtype=dtype, device=gpu, x3=x3)
     return onet, hnet
 
 
@@ -167,16 +167,33 @@ def test_unet_full_size_modulated_64x64(gpu, hook):
     ref = None
     from freefine_amd.config import UNetConfig
     from freefine_amd.unet import HipUNet
-    for dtype, tol in ((torch.float32, 2e-4), (torch.bfloat16, 6e-2)):
-        hnet = HipUNet(UNetConfig.preset("sd21-base"), onet.state_dict(), dtype=dtype, device=gpu)
+    for dtype, x3, tol in ((torch.float32, False, 2e-4), (torch.float32, True, 2e-4), (torch.bfloat16, False, 6e-2)):
+        hnet = HipUNet(UNetConfig.preset("sd21-base"), onet.state_dict(), dtype=dtype, device=gpu, x3=x3)
         _, _, om, hc = setup_pair(hook, "tca", gpu, dtype, name="sd21-base", size=512, pair=(onet, hnet))
         if ref is None:
             ref = onet(x, torch.tensor(481), enc)
             assert (om.cur_att_layer, om.cur_step) == (0, 1)
         out = hnet(x.to(gpu), 481, enc.to(gpu))
         err = relerr(out, ref)
-        print(f"full-size sd21-base @64x64, hook={hook}/tca, {dtype}: max |diff| / max |ref| = {err:.3e}")
+        print(f"full-size sd21-base @64x64, hook={hook}/tca, {dtype}{' split-bf16' if x3 else ''}: max |diff| / max |ref| = {err:.3e}")
         assert err < tol, (hook, dtype)
         assert (hc.cur_att_layer, hc.cur_step) == (0, 1)
         del hnet
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny-conv"])
+def test_unet_split_bf16_mode(gpu, name):
+    """the split-bf16 mode (fp32 activations, FFN_BF16X3 GEMMs) on the tiny topologies, plain and with the edit hooks: it must hold the
+    PARITY tolerance of the fp32 mode (1e-4 of the output scale), not the fast mode's."""
+    onet, hnet = build(name, torch.float32, gpu, x3=True)
+    D = onet.cfg.cross_attention_dim
+    x, enc = rng_tensor(1, (2, 4, 16, 16)), rng_tensor(2, (2, 77, D))
+    ref = onet(x, torch.tensor(481), enc)
+    err = relerr(hnet(x.to(gpu), 481, enc.to(gpu)), ref)
+    print(f"split-bf16 {name}: {err:.2e}")
+    assert err < 1e-4
+    onet, hnet, om, hc = setup_pair("edit", "tca", gpu, torch.float32, name=name, pair=build(name, torch.float32, gpu, x3=True))
+    x, enc = rng_tensor(3, (4, 4, 16, 16)), rng_tensor(4, (4, 77, D))
+    ref = onet(x, torch.tensor(481), enc)
+    assert relerr(hnet(x.to(gpu), 481, enc.to(gpu)), ref) < 1e-4
