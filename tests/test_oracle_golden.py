@@ -63,9 +63,11 @@ def g1_oracle_outputs(ci, heads, d, S, kind, cg):
 def test_g1_attention_modulation():
     g = np.load(os.path.join(GOLD, "g1_attention.npz"))
     ncase = len([k for k in g.files if k.endswith("_meta")])
-    assert ncase == 8
+    assert ncase == 10
+    nup = 0
     for ci in range(ncase):
-        heads, d, S, is_float = (int(v) for v in g[f"c{ci}_meta"])
+        heads, d, S, is_float, upcast = (int(v) for v in g[f"c{ci}_meta"])
+        nup += upcast       # cases 8, 9: the reference ran with upcast_attention = upcast_softmax = True (fp32 model: same maths, other code path)
         cg = float(g[f"c{ci}_cg"][0])
         outs = g1_oracle_outputs(ci, heads, d, S, "float" if is_float else "uint8", cg)
         for name, o in outs.items():
@@ -74,6 +76,7 @@ def test_g1_attention_modulation():
             s1, s2 = g[f"c{ci}_{name}_sum"]
             assert abs(o.double().sum().item() - s1) < 1e-3 * (1 + abs(s1)), (ci, name)
             assert abs(o.double().pow(2).sum().item() - s2) < 1e-4 * (1 + abs(s2)), (ci, name)
+    assert nup == 2
 
 
 def test_g3_scheduler_steps():
@@ -152,3 +155,32 @@ def test_g6_unet_vs_intree_ldm():
     x, ctx = rng_tensor(31, (2, 4, 16, 16)), rng_tensor(32, (2, 77, cfg.cross_attention_dim))
     y = net(x, torch.tensor(int(g["t"][0])), ctx)
     assert (y - torch.from_numpy(g["y"])).abs().max().item() < 2e-5
+
+
+def test_g6b_unet_linear_proj_and_per_level_heads_vs_intree_sgm():
+    """SD-2.1's deltas from SD-1.x -- LINEAR proj_in / proj_out and head counts that follow a constant head width -- pinned against
+    the in-tree Stability sgm UNetModel (generative-models/sgm/modules/diffusionmodules/openaimodel.py, num_head_channels=16,
+    use_linear_in_transformer=True)."""
+    from oracle import sd_unet
+    g = np.load(os.path.join(GOLD, "g6b_sgm_unet.npz"))
+    cfg = sd_unet.unet_config("tiny")
+    cfg.norm_num_groups, cfg.heads = 32, tuple(int(h) for h in g["heads"])
+    assert cfg.use_linear_projection and cfg.heads == (2, 4, 8, 8)
+    net = sd_unet.init_unet(cfg, seed=5)
+    x, ctx = rng_tensor(41, (2, 4, 16, 16)), rng_tensor(42, (2, 77, cfg.cross_attention_dim))
+    y = net(x, torch.tensor(int(g["t"][0])), ctx)
+    assert (y - torch.from_numpy(g["y"])).abs().max().item() < 2e-5
+
+
+def test_g7_vae_vs_intree_ldm_encoder_decoder():
+    """the VAE restatement against the in-tree CompVis Encoder / Decoder (evaluation/MotionGuidance/ldm/modules/diffusionmodules/
+    model.py:368, 462): encoder moments (before quant_conv) and decoder output on seeded inputs, ragged 64x48 image."""
+    from types import SimpleNamespace
+    from oracle import sd_vae
+    g = np.load(os.path.join(GOLD, "g7_ldm_vae.npz"))
+    cfg = SimpleNamespace(name="g7", in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(32, 64, 128, 128),
+                          layers_per_block=2, norm_num_groups=32, scaling_factor=0.18215)
+    vae = sd_vae.init_vae(cfg, seed=9)
+    x, z = rng_tensor(51, (2, 3, 64, 48)), rng_tensor(52, (2, 4, 8, 6))
+    assert (vae.encoder(x) - torch.from_numpy(g["moments"])).abs().max().item() < 2e-5
+    assert (vae.decoder(z) - torch.from_numpy(g["dec"])).abs().max().item() < 5e-5

@@ -308,3 +308,29 @@ def test_split_bf16_mode_meets_parity_on_whole_loops(gpu):
     dev = traj_dev(model.last_intermediates, g[f"{name}_traj"])
     print(f"split-bf16 {name}: latent L-inf vs reference golden {dev:.2e}")
     assert dev < TOL
+
+
+def test_vae_full_size_vs_oracle(gpu):
+    """the SD VAE topology (128-256-512-512, 83.7 M parameters) at 512x512: encode (latent mean x 0.18215) and decode (-> [0,1] image)
+    on HIP against the oracle VAE, itself pinned to the in-tree CompVis Encoder / Decoder by tests/golden/g7_ldm_vae.npz.
+    fp32 parity mode <= 2e-4 of the output scale; the bf16 fast mode's deviation is printed and bounded."""
+    from freefine_amd.config import VAEConfig
+    from freefine_amd.vae import HipVAE
+    from oracle import sd_vae
+    torch.set_num_threads(max(8, min(32, torch.get_num_threads())))
+    ov = sd_vae.init_vae(sd_vae.vae_config("sd"), seed=1)
+    img = np.random.default_rng(5).integers(0, 256, (1, 512, 512, 3), dtype=np.uint8)
+    x = (torch.from_numpy(img).float() / 127.5 - 1).permute(0, 3, 1, 2)
+    ref = ov.encode_mean(x) * 0.18215
+    dref = (ov.decode(ref / 0.18215) / 2 + 0.5).clamp(0, 1)
+    for dtype, tol in ((torch.float32, 2e-4), (torch.bfloat16, 5e-2)):
+        hv = HipVAE(VAEConfig.preset("sd"), ov.state_dict(), dtype=dtype, device=gpu)
+        out = hv.encode_mean_scaled(img_u8=torch.from_numpy(img)).cpu()
+        e_enc = ((out - ref).abs().max() / ref.abs().max()).item()
+        dout = hv.decode_image(ref.to(gpu)).cpu()
+        e_dec = (dout - dref).abs().max().item()
+        print(f"SD VAE @512^2 {dtype}: encode max |diff| / max |ref| = {e_enc:.2e}, decode max |diff| (image in [0,1]) = {e_dec:.2e}")
+        assert out.shape == ref.shape == (1, 4, 64, 64) and dout.shape == dref.shape == (1, 3, 512, 512)
+        assert e_enc < tol and e_dec < 2 * tol
+        del hv
+        torch.cuda.empty_cache()

@@ -38,7 +38,11 @@ def g1_cases():
     for (heads, d) in ((8, 8), (5, 16)):
         for S in (64, 256):
             for mask_kind in ("uint8", "float"):
-                cases.append(dict(heads=heads, d=d, S=S, mask_kind=mask_kind))
+                cases.append(dict(heads=heads, d=d, S=S, mask_kind=mask_kind, upcast=False))
+    # SD-2.1's unet config sets upcast_attention: the fp32 casts of get_attention_scores (attention.py:776-778, 798-799) taken in an
+    # fp32 model (the only precision the masked branches work in with that flag)
+    cases.append(dict(heads=5, d=16, S=64, mask_kind="uint8", upcast=True))
+    cases.append(dict(heads=8, d=8, S=256, mask_kind="float", upcast=True))
     return cases
 
 
@@ -70,7 +74,7 @@ def run_g1(A):
 
         def fresh(method=None):
             m = A.Attention_Modulator(start_layer=10)
-            m.heads, m.scale, m.upcast_attention, m.upcast_softmax = heads, scale, False, False
+            m.heads, m.scale, m.upcast_attention, m.upcast_softmax = heads, scale, c["upcast"], c["upcast"]
             m.num_att_layers = 32
             m.cur_att_layer = 20  # block 10, inside layer_idx
             m.method, m.context_guidance = method, cg
@@ -116,7 +120,7 @@ def run_g1(A):
             devs.append((ci, name, (orc[name] - r).abs().max().item()))
             out[f"c{ci}_{name}_sub"] = r[:, ::5, ::3].numpy().copy()
             out[f"c{ci}_{name}_sum"] = np.array([r.double().sum().item(), r.double().pow(2).sum().item()])
-        out[f"c{ci}_meta"] = np.array([heads, d, S, int(c["mask_kind"] == "float")])
+        out[f"c{ci}_meta"] = np.array([heads, d, S, int(c["mask_kind"] == "float"), int(c["upcast"])])
         out[f"c{ci}_cg"] = np.array([cg])
     np.savez_compressed(os.path.join(GOLD, "g1_attention.npz"), **out)
     worst = max(devs, key=lambda t: t[2])
@@ -443,8 +447,120 @@ def run_g6():
     print(f"[G6] oracle UNet vs in-tree ldm UNetModel: max abs diff {dev:.3e} (|y|max {y_ldm.abs().max():.3f})")
 
 
+def _bare_package(name, path):
+    """register `name` as a package WITHOUT running its __init__ (sgm/__init__.py pulls pytorch_lightning / open_clip for model
+    classes this script never touches); submodules then import from `path` as usual"""
+    import types
+    m = types.ModuleType(name)
+    m.__path__ = [path]
+    sys.modules[name] = m
+
+
+def run_g6b():
+    """SD-2.1's two structural deltas from SD-1.x, pinned against the in-tree Stability `sgm` UNetModel
+    (generative-models/sgm/modules/diffusionmodules/openaimodel.py:504 ff.): per-level head COUNTS from a constant head width
+    (num_head_channels) and a LINEAR proj_in / proj_out in the transformer (use_linear_in_transformer)."""
+    R = os.path.join(RH.REF, "generative-models", "sgm")
+    _bare_package("sgm", R)
+    _bare_package("sgm.modules", os.path.join(R, "modules"))
+    _bare_package("sgm.modules.diffusionmodules", os.path.join(R, "modules", "diffusionmodules"))
+    from sgm.modules.diffusionmodules.openaimodel import UNetModel
+    from oracle import sd_unet
+    cfg = sd_unet.unet_config("tiny")             # use_linear_projection=True
+    cfg.norm_num_groups = 32
+    cfg.heads = (2, 4, 8, 8)                      # 32, 64, 128, 128 channels / 16 per head
+    assert cfg.use_linear_projection
+    net = sd_unet.init_unet(cfg, seed=5)
+    ref = UNetModel(in_channels=4, model_channels=32, out_channels=4, num_res_blocks=2, attention_resolutions=[4, 2, 1],
+                    channel_mult=[1, 2, 4, 4], num_head_channels=16, transformer_depth=1, context_dim=cfg.cross_attention_dim,
+                    use_checkpoint=False, use_linear_in_transformer=True, spatial_transformer_attn_type="softmax").eval()
+    sd = to_ldm_state(cfg, net.state_dict())
+    missing, unexpected = ref.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing[:5], unexpected[:5])
+    x = rng_tensor(41, (2, 4, 16, 16))
+    ctx = rng_tensor(42, (2, 77, cfg.cross_attention_dim))
+    with torch.no_grad():
+        y_ref = ref(x, torch.tensor([301, 301]), context=ctx)
+        y = net(x, torch.tensor(301), ctx)
+    dev = (y - y_ref).abs().max().item()
+    np.savez_compressed(os.path.join(GOLD, "g6b_sgm_unet.npz"), y=y_ref.numpy(), t=np.array([301]), heads=np.array(cfg.heads))
+    print(f"[G6b] oracle UNet (linear proj_in, per-level heads {cfg.heads}) vs in-tree sgm UNetModel: max abs diff {dev:.3e} "
+          f"(|y|max {y_ref.abs().max():.3f})")
+
+
+def vae_ldm_state(cfg, sd):
+    """oracle (diffusers-layout) AutoencoderKL names -> ldm Encoder / Decoder names (two dicts); quant convs stay outside (they live in
+    ldm's AutoencoderKL wrapper, which needs pytorch_lightning)."""
+    n = len(cfg.block_out_channels)
+    enc, dec = {}, {}
+    attn = {"group_norm": "norm", "to_q": "q", "to_k": "k", "to_v": "v", "to_out.0": "proj_out"}
+    for k, v in sd.items():
+        side, rest = k.split(".", 1)
+        if side not in ("encoder", "decoder"):
+            continue
+        dst = enc if side == "encoder" else dec
+        parts = rest.split(".")
+        if parts[0] in ("down_blocks", "up_blocks"):
+            lvl = int(parts[1]) if side == "encoder" else n - 1 - int(parts[1])
+            top = "down" if side == "encoder" else "up"
+            if parts[2] == "resnets":
+                leaf = ".".join(parts[4:]).replace("conv_shortcut", "nin_shortcut")
+                name = f"{top}.{lvl}.block.{parts[3]}.{leaf}"
+            else:
+                name = f"{top}.{lvl}.{'downsample' if side == 'encoder' else 'upsample'}.conv.{parts[-1]}"
+        elif parts[0] == "mid_block":
+            if parts[1] == "resnets":
+                name = f"mid.block_{int(parts[2]) + 1}." + ".".join(parts[3:]).replace("conv_shortcut", "nin_shortcut")
+            else:
+                sub = ".".join(parts[3:-1])
+                name = f"mid.attn_1.{attn[sub]}.{parts[-1]}"
+                if sub != "group_norm" and parts[-1] == "weight":
+                    v = v[:, :, None, None]            # ldm's AttnBlock uses 1x1 convolutions
+        elif parts[0] == "conv_norm_out":
+            name = "norm_out." + parts[1]
+        else:
+            name = rest
+        dst[name] = v
+    return enc, dec
+
+
+def run_g7():
+    """the VAE restatement (oracle/sd_vae.py, diffusers-0.18 AutoencoderKL layout) against the in-tree CompVis Encoder / Decoder
+    (evaluation/MotionGuidance/ldm/modules/diffusionmodules/model.py:368, 462) on key-mapped seeded weights."""
+    from types import SimpleNamespace
+    import types
+    if "omegaconf" not in sys.modules:
+        om, oml = types.ModuleType("omegaconf"), types.ModuleType("omegaconf.listconfig")
+        oml.ListConfig = type("ListConfig", (list,), {})
+        om.listconfig = oml
+        sys.modules["omegaconf"], sys.modules["omegaconf.listconfig"] = om, oml
+    mg = os.path.join(RH.REF, "evaluation", "MotionGuidance")
+    if mg not in sys.path:
+        sys.path.insert(0, mg)
+    from ldm.modules.diffusionmodules.model import Decoder, Encoder
+    from oracle import sd_vae
+    cfg = SimpleNamespace(name="g7", in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(32, 64, 128, 128),
+                          layers_per_block=2, norm_num_groups=32, scaling_factor=0.18215)
+    vae = sd_vae.init_vae(cfg, seed=9)
+    kw = dict(ch=32, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=[], dropout=0.0, in_channels=3, resolution=64, z_channels=4)
+    enc, dec = Encoder(double_z=True, **kw).eval(), Decoder(**kw).eval()
+    se, sdv = vae_ldm_state(cfg, vae.state_dict())
+    for mod, st in ((enc, se), (dec, sdv)):
+        missing, unexpected = mod.load_state_dict(st, strict=False)
+        assert not missing and not unexpected, (missing[:5], unexpected[:5])
+    x = rng_tensor(51, (2, 3, 64, 48))
+    z = rng_tensor(52, (2, 4, 8, 6))
+    with torch.no_grad():
+        m_ref, d_ref = enc(x), dec(z)
+        m_or, d_or = vae.encoder(x), vae.decoder(z)
+    de, dd = (m_or - m_ref).abs().max().item(), (d_or - d_ref).abs().max().item()
+    np.savez_compressed(os.path.join(GOLD, "g7_ldm_vae.npz"), moments=m_ref.numpy(), dec=d_ref.numpy())
+    print(f"[G7] oracle VAE vs in-tree ldm Encoder / Decoder: encoder max abs diff {de:.3e} (|y|max {m_ref.abs().max():.3f}), "
+          f"decoder {dd:.3e} (|y|max {d_ref.abs().max():.3f})")
+
+
 if __name__ == "__main__":
-    only = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6"]
+    only = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g6b", "g7"]
     torch.set_grad_enabled(False)
     A, Mo = RH.import_reference()
     if "g1" in only:
@@ -457,3 +573,7 @@ if __name__ == "__main__":
         run_g5(A, Mo)
     if "g6" in only:
         run_g6()
+    if "g6b" in only:
+        run_g6b()
+    if "g7" in only:
+        run_g7()
