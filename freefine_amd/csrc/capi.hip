@@ -12,6 +12,7 @@
 #include "attention.h"
 #include "attention_pp.h"
 #include "attention_x.h"
+#include "attention_x3.h"
 #include "elementwise.h"
 #include "igemm.h"
 #include "igemm_p8.h"
@@ -960,9 +961,22 @@ static int launch_xattn(hipStream_t s, const ffn_attn_desc& d, int nkf, int mult
     else LAUNCH(xattn_kernel<6>, grid, dim3(256), 0, s, d, wpp, bpw);
     return check_launch("attn(cross)");
 }
+static bool attn_has_masks(const ffn_attn_desc& d) {
+    for (int pi = 0; pi < d.npass; ++pi)
+        for (int b = 0; b < d.Bo; ++b) {
+            const ffn_attn_entry& e = d.e[pi * FFN_ATT_MAXB + b];
+            if ((e.w_const != 0.f || e.w_slope != 0.f) && e.kmask) return true;
+        }
+    return false;
+}
 extern "C" int ffn_attn_kernel_name(int dtype, const ffn_attn_desc* d, char* buf, int len) {
     REQUIRE(d && buf && len > 0, "attn_kernel_name: null argument");
     int dp = 0, qf = 0;
+    if (dtype == FFN_BF16X3 && d->D <= 64) {
+        snprintf(buf, len, "void attn_x3_kernel<%s>(ffn_attn_desc)", attn_has_masks(*d) ? "true" : "false");
+        return FFN_OK;
+    }
+    if (dtype == FFN_BF16X3) dtype = FFN_F32;
     ffn_attn_variant(dtype, d->D, &dp, &qf);
     if (dtype == FFN_F32) {
         snprintf(buf, len, "void attn_kernel<float, %d, %d, %d, 1, true>(ffn_attn_desc)", dp, qf, dp == 160 ? 32 : 64);
@@ -981,8 +995,8 @@ extern "C" int ffn_attn_kernel_name(int dtype, const ffn_attn_desc* d, char* buf
 }
 extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
     REQUIRE(d, "attn: null descriptor");
-    REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "attn: bad dtype %d", dtype);
-    const int epc = dtype == FFN_F32 ? 4 : 8;
+    REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16 || dtype == FFN_BF16X3, "attn: bad dtype %d", dtype);
+    const int epc = dtype == FFN_BF16 ? 8 : 4;
     REQUIRE(d->q && d->k && d->vt && d->out, "attn: null q/k/vt/out");
     REQUIRE(aligned16(d->q) && aligned16(d->k) && aligned16(d->vt) && aligned16(d->out), "attn: pointers must be 16-byte aligned");
     REQUIRE(d->Bo > 0 && d->Bo <= FFN_ATT_MAXB, "attn: Bo=%d out of range (max %d)", d->Bo, FFN_ATT_MAXB);
@@ -993,6 +1007,20 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
     REQUIRE(d->ldvt >= d->Sk, "attn: ldvt=%d < Sk=%d", d->ldvt, d->Sk);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int D = d->D;
+    if (dtype == FFN_BF16X3 && D <= 64) {      // split-bf16 arithmetic on fp32 operands (attention_x3.h); other head sizes: the exact fp32 kernel
+        constexpr int lds = 2 * (4 * 8192) + 8 * 4 * 2 * 64 * 16;
+        dim3 grid(((d->S + 255) / 256) * d->heads * d->Bo);
+        int rc;
+        if (attn_has_masks(*d)) {
+            if ((rc = set_lds(attn_x3_kernel<true>, lds))) return rc;
+            LAUNCH(attn_x3_kernel<true>, grid, dim3(512), lds, s, *d);
+        } else {
+            if ((rc = set_lds(attn_x3_kernel<false>, lds))) return rc;
+            LAUNCH(attn_x3_kernel<false>, grid, dim3(512), lds, s, *d);
+        }
+        return check_launch("attn(split-bf16)");
+    }
+    if (dtype == FFN_BF16X3) dtype = FFN_F32;
     if (dtype == FFN_F32) {
         if (D <= 48) return launch_attn<float, 48, 2>(s, *d);
         if (D <= 64) return launch_attn<float, 64, 2>(s, *d);

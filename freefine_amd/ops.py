@@ -283,7 +283,7 @@ class AttnEntrySpec:
                              self.flags, logical_row if self.hr_row is None else self.hr_row)
 
 
-def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=None, Bo=None, C=None):
+def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=None, Bo=None, C=None, x3=False):
     """q: [Bq,S,C]; k: [Bk,Sk,C]; vt: [Bk,C,ldvt] (V transposed).  passes: list (per pass) of lists (per output
     row) of AttnEntrySpec or None (= skipped).  passes=None -> plain attention, row b uses its own K/V.
     More than FFN_ATT_MAXB output rows are issued as several launches over row ranges (entries name absolute Q/KV rows)."""
@@ -300,6 +300,7 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
     for rows in passes:
         assert len(rows) == Bo
     esz = q.element_size()
+    dcode = L.FFN_BF16X3 if (x3 and q.dtype == torch.float32) else _dt(q)      # split-bf16 arithmetic on fp32 operands
     for b0 in range(0, Bo, L.ATT_MAXB):
         nb = min(L.ATT_MAXB, Bo - b0)
         d = L.AttnDesc()
@@ -321,14 +322,14 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
                 hr = sp.hr_row if sp.hr_row is not None else (b0 + b if b0 else None)
                 e.hr_row = 0 if hr is None else hr + 1
         if _PROF is None:
-            L.check(lib.ffn_attn(_stream(), _dt(q), CT.byref(d)), "ffn_attn")
+            L.check(lib.ffn_attn(_stream(), dcode, CT.byref(d)), "ffn_attn")
         else:
             nterms = sum(1 for rows in passes for sp in rows[b0:b0 + nb] if sp is not None and (sp.w_const != 0.0 or sp.w_slope != 0.0))
             nbuf = CT.create_string_buffer(160)
-            lib.ffn_attn_kernel_name(_dt(q), CT.byref(d), nbuf, 160)
+            lib.ffn_attn_kernel_name(dcode, CT.byref(d), nbuf, 160)
             L.check(_timed(nbuf.value.decode(), 4.0 * nterms * S * Sk * Cq,
                            esz * nterms * (S * Cq + 2 * Sk * Cq) + esz * nb * S * Cq,
-                           lambda: lib.ffn_attn(_stream(), _dt(q), CT.byref(d))), "ffn_attn")
+                           lambda: lib.ffn_attn(_stream(), dcode, CT.byref(d))), "ffn_attn")
     return out
 
 

@@ -374,15 +374,15 @@ class HipUNet:
         D = t.C // t.heads
         scale = D ** -0.5
         if self.controller is None:
-            return ops.attention(q, k, vt, t.heads, scale, None, Sk=Sk, C=t.C)
+            return ops.attention(q, k, vt, t.heads, scale, None, Sk=Sk, C=t.C, x3=self.x3)
         plan = self._plan(is_cross, place, B, S, t.heads)
         if plan["kind"] == "shared_kv":
             rr = plan["ref_rows"]
             kc = k[..., :t.C] if k.shape[-1] != t.C else k
             k2 = torch.cat([kc, kc[rr]], dim=1).contiguous()                 # device-memory plumbing (non-default SSA/SDSA path)
             vt2 = torch.cat([vt[..., :Sk], vt[rr][..., :Sk]], dim=2).contiguous()
-            return ops.attention(q, k2, vt2, t.heads, scale, plan["passes"], Sk=2 * Sk, C=t.C)
-        return ops.attention(q, k, vt, t.heads, scale, plan["passes"], Sk=Sk, C=t.C, w_dev=self.cg_dev if plan["needs_cg"] else None)
+            return ops.attention(q, k2, vt2, t.heads, scale, plan["passes"], Sk=2 * Sk, C=t.C, x3=self.x3)
+        return ops.attention(q, k, vt, t.heads, scale, plan["passes"], Sk=Sk, C=t.C, w_dev=self.cg_dev if plan["needs_cg"] else None, x3=self.x3)
 
     def _transformer_block(self, t, x, B, H, W, place, kv_text, out=None):
         S, C = H * W, t.C

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-enum { FFN_F32 = 0, FFN_BF16 = 1, FFN_BF16X3 = 2 /* ffn_igemm only: split-bf16 operands, fp32 results (see ffn_igemm) */ };
+enum { FFN_F32 = 0, FFN_BF16 = 1, FFN_BF16X3 = 2 /* ffn_igemm / ffn_attn: split-bf16 arithmetic, fp32 results (see ffn_igemm) */ };
 enum { FFN_OK = 0, FFN_EINVAL = -22, FFN_ENOSYS = -38, FFN_EHIP = -5 };
 
 int ffn_version(void);
@@ -142,6 +142,8 @@ typedef struct ffn_attn_desc {
     ffn_attn_entry e[FFN_ATT_MAXP * FFN_ATT_MAXB]; /* entry (p,b) at p*FFN_ATT_MAXB + b */
 } ffn_attn_desc;
 int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d);
+/* dtype FFN_BF16X3: q / k / vt / out are fp32 exactly as with FFN_F32; head sizes D <= 64 run attn_x3_kernel (attention_x3.h: both
+ * products in split-bf16 arithmetic, three bf16 MFMAs per term, fp32 softmax), larger heads fall back to the exact fp32 kernel. */
 /* bf16 launches with D = 64, Sk % 64 == 0, S >= 128 and no degenerate (uniform-softmax) entry run attn_pp_kernel (attention_pp.h:
  * software-pipelined, 8 waves in two alternating groups); everything else attn_kernel (attention.h).  Same results up to fp32
  * summation order.  FFN_ATTN_PP=0 in the environment forces attn_kernel.

@@ -869,3 +869,86 @@ def test_x3_every_configuration_and_determinism(gpu):
     ref = ops.conv3x3(x, w, b, B, H, H, Cin, residual=r).clone()
     for _ in range(4):
         assert torch.equal(ops.conv3x3(x, w, b, B, H, H, Cin, residual=r), ref)
+
+
+@pytest.mark.parametrize("S,Sk,heads,D", [(256, 256, 5, 64), (64, 77, 8, 40), (200, 130, 4, 16), (100, 77, 2, 8), (128, 64, 2, 160)])
+def test_x3_attention_plain_and_cross(gpu, S, Sk, heads, D):
+    """attn_x3_kernel (fp32 operands, split-bf16 products): plain self / cross attention, ragged S and Sk, head sizes below 64 (zero
+    padded) and one above (falls back to the exact fp32 kernel), row remaps with a device-scalar weight."""
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(S + D)
+    dt = torch.float32
+    B, Cc = 3, heads * D
+    q, k, v = rnd((B, S, Cc), dt, gpu, g), rnd((2, Sk, Cc), dt, gpu, g), rnd((2, Sk, Cc), dt, gpu, g)
+    vt = ops.transpose(v, ld_dst=(Sk + 7) // 8 * 8)
+    scale = D ** -0.5
+    cg = torch.tensor([0.25], device=gpu)
+    rows = [ops.AttnEntrySpec(2, 1, 1.0, 0.0), ops.AttnEntrySpec(0, 0, 0.5, 2.0), ops.AttnEntrySpec(1, 1, 1.0, 0.0), ops.AttnEntrySpec(2, 0, 1.0, 0.0)]
+    out = ops.attention(q, k, vt, heads, scale, [rows], Sk=Sk, w_dev=cg, x3=True)
+    assert out.dtype == torch.float32
+    worst = 0.0
+    for b, sp in enumerate(rows):
+        ref = (sp.w_const + sp.w_slope * 0.25) * ref_attention(q[sp.q_row].double().cpu(), k[sp.kv_row].double().cpu(), v[sp.kv_row].double().cpu(), heads, scale)
+        worst = max(worst, relerr(out[b], ref))
+    print(f"x3 attention S={S} Sk={Sk} h={heads} d={D}: {worst:.2e}")
+    assert worst < X3_TOL
+
+
+@pytest.mark.parametrize("hook", ["edit", "bggen"])
+@pytest.mark.parametrize("S,heads", [(4096, 5), (1024, 10), (200, 3)])
+def test_x3_attention_tca(gpu, hook, S, heads):
+    """the TCA pass tables (reference rows, key mask, query selector, tiled-head rule, context-guidance blend) through attn_x3_kernel
+    at the production shapes and a ragged one, against the fp64 statement"""
+    from freefine_amd import ops
+    from freefine_amd._lib import ATT_HEAD_RULE
+    g = torch.Generator().manual_seed(S + heads)
+    dt, B, D = torch.float32, 4, 64
+    Cc = heads * D
+    q, k, v = rnd((B, S, Cc), dt, gpu, g), rnd((B, S, Cc), dt, gpu, g), rnd((B, S, Cc), dt, gpu, g)
+    vt = ops.transpose(v, ld_dst=(S + 7) // 8 * 8)
+    src, tgt = (torch.rand(S, generator=g) > 0.6).to(torch.uint8), (torch.rand(S, generator=g) > 0.5).to(torch.uint8)
+    cg = 0.35
+    cg_dev = torch.tensor([cg], dtype=torch.float32, device=gpu)
+    scale = D ** -0.5
+    ref_rows = [1, 1, 3, 3]
+    if hook == "edit":
+        p_ref = [ops.AttnEntrySpec(b, ref_rows[b], 0.0, 1.0, kmask=src.to(gpu), qsel=tgt.to(gpu), flags=ATT_HEAD_RULE) for b in range(B)]
+    else:
+        p_ref = [ops.AttnEntrySpec(b, ref_rows[b], 0.0, 1.0, kmask=(1 - src).to(gpu), flags=ATT_HEAD_RULE) for b in range(B)]
+    p_self = [ops.AttnEntrySpec(b, b, 1.0, -1.0) for b in range(B)]
+    out = ops.attention(q, k, vt, heads, scale, [p_ref, p_self], w_dev=cg_dev, Sk=S, x3=True)
+    qd, kd, vd = q.double(), k.double(), v.double()
+    sg, tg = src.to(gpu), tgt.to(gpu)
+    a_even = ((sg[None, :] != 0) == (tg[:, None] != 0)) if hook == "edit" else (sg[None, :] == 0).expand(S, S)
+    worst = 0.0
+    for b in range(B):
+        allowed = [a_even if (b * heads + h) % 2 == 0 else None for h in range(heads)]
+        r = _ref_attention_gpu(qd[b], kd[ref_rows[b]], vd[ref_rows[b]], heads, scale, allowed)
+        s_ = _ref_attention_gpu(qd[b], kd[b], vd[b], heads, scale)
+        worst = max(worst, relerr(out[b], cg * r + (1 - cg) * s_))
+    print(f"x3 TCA {hook} S={S} h={heads}: {worst:.2e}")
+    assert worst < X3_TOL
+
+
+def test_x3_attention_uniform_wq_and_determinism(gpu):
+    from freefine_amd import ops
+    from freefine_amd._lib import ATT_UNIFORM_SEL1
+    g = torch.Generator().manual_seed(22)
+    dt = torch.float32
+    B, S, Sk, heads, D = 3, 100, 77, 8, 40
+    Cc = heads * D
+    q, k, v = rnd((B, S, Cc), dt, gpu, g), rnd((B, Sk, Cc), dt, gpu, g), rnd((B, Sk, Cc), dt, gpu, g)
+    vt = ops.transpose(v, ld_dst=80)
+    scale = D ** -0.5
+    km = torch.zeros(Sk, dtype=torch.uint8, device=gpu)
+    wq = torch.rand(S, generator=g).to(gpu)
+    p0 = [ops.AttnEntrySpec(0, 0, 1.0, 0.0, kmask=km, flags=ATT_UNIFORM_SEL1), ops.AttnEntrySpec(1, 1), ops.AttnEntrySpec(2, 2, wq=wq)]
+    p1 = [None, None, ops.AttnEntrySpec(0, 1, 0.5)]
+    out = ops.attention(q, k, vt, heads, scale, [p0, p1], Sk=Sk, x3=True)
+    qc, kc, vc = q.double().cpu(), k.double().cpu(), v.double().cpu()
+    assert relerr(out[0], vc[0].mean(dim=0, keepdim=True).expand(S, Cc)) < X3_TOL
+    assert relerr(out[1], ref_attention(qc[1], kc[1], vc[1], heads, scale)) < X3_TOL
+    ref2 = wq.double().cpu()[:, None] * ref_attention(qc[2], kc[2], vc[2], heads, scale) + 0.5 * ref_attention(qc[0], kc[1], vc[1], heads, scale)
+    assert relerr(out[2], ref2) < X3_TOL
+    for _ in range(3):
+        assert torch.equal(ops.attention(q, k, vt, heads, scale, [p0, p1], Sk=Sk, x3=True), out)
