@@ -276,6 +276,12 @@ class AttnEntrySpec:
         return AttnEntrySpec(row_map[self.q_row], row_map[self.kv_row], self.w_const, self.w_slope, self.wq, self.kmask, self.qsel,
                              self.flags, logical_row if self.hr_row is None else self.hr_row)
 
+    def renumber(self, ren):
+        """the same term inside a launch that holds only a SUBSET of the physical rows (`ren`: physical row -> row of that launch)"""
+        if self.q_row not in ren or self.kv_row not in ren:
+            raise ValueError(f"attention term (q row {self.q_row}, kv row {self.kv_row}) reaches outside the rows of this phase {sorted(ren)}")
+        return AttnEntrySpec(ren[self.q_row], ren[self.kv_row], self.w_const, self.w_slope, self.wq, self.kmask, self.qsel, self.flags, self.hr_row)
+
     def shifted(self, base, logical_row):
         """the same term inside an image-batched launch: this image's physical rows start at `base`; the tiled-head rule
         (attention.py:859 vs 761) keeps using the row index the image would have had in its own batch"""

@@ -56,6 +56,10 @@ class FreeFinePipeline:
         self._mask_dev = {}
         self._batch_ctrls = {}
         self.dedup_rows = True      # exact: identical (latent, text) rows of the CFG batch are evaluated once
+        # exact: the guided loop's reference row re-enters the UNet from the state the inversion pass recorded for the same (latent,
+        # timestep, "") triple instead of being recomputed from conv_in (HipUNet.forward, `reuse`); off = recompute like the reference
+        self.reuse_ref_stream = True
+        self._ref_cache = None
 
     # ------------------------------------------------------------------------------------------------------------
     # construction (freefine_batch_infer_2d.py:148-157)
@@ -135,7 +139,7 @@ class FreeFinePipeline:
         separate HIP streams; give it its own controller with register_attention_control*."""
         other = FreeFinePipeline(self.unet.share(), self.vae, self.tokenizer, self.text_encoder,
                                  DDIMScheduler.from_config(self.scheduler.config), self.device)
-        other.noise_device, other.dedup_rows = self.noise_device, self.dedup_rows
+        other.noise_device, other.dedup_rows, other.reuse_ref_stream = self.noise_device, self.dedup_rows, self.reuse_ref_stream
         return other
 
     def _seed(self, seed):
@@ -270,9 +274,16 @@ class FreeFinePipeline:
     # loops
     # ------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
+    def _min_tca_block(self):
+        """first transformer block whose self-attention the registered controller(s) may modulate (None: none)"""
+        cs = self.unet._ctrls() or ([self.controller] if self.controller is not None else [])
+        idx = [min(c.layer_idx) for c in cs if getattr(c, "layer_idx", None)]
+        return min(idx) if idx else None
+
     def invert(self, image, prompt, num_inference_steps=50, num_actual_inference_steps=None, guidance_scale=7.5, eta=0.0,
-               return_intermediates=False, verbose=False, **kwds):
-        """model.py:816-925 (HOT LOOP 1)"""
+               return_intermediates=False, verbose=False, record_rows=None, **kwds):
+        """model.py:816-925 (HOT LOOP 1).  record_rows (reference-stream reuse): batch rows whose state at the UNet's join point
+        is recorded at every step for the guided loop that follows (self._ref_cache)."""
         batch_size = image.shape[0]
         if isinstance(prompt, list):
             if batch_size == 1:
@@ -286,19 +297,50 @@ class FreeFinePipeline:
             self.controller.use_cfg = True
         self.scheduler.set_timesteps(num_inference_steps)
         latents_list = [latents]
+        cache = None
+        self._ref_cache = None
+        if record_rows and self.reuse_ref_stream and not guidance_scale > 1. and hasattr(self.unet, "join_block"):
+            join, _ = self.unet.join_block(self._min_tca_block())
+            cache = dict(join=join, rows=list(record_rows), slots=[], latents=latents_list, text=text[list(record_rows)].clone(),
+                         idx=torch.tensor(list(record_rows), device=self.device))
         for i, t in enumerate(reversed(self.scheduler.timesteps)):
             if num_actual_inference_steps is not None and i >= num_actual_inference_steps:
                 continue
             model_inputs = torch.cat([latents] * 2) if guidance_scale > 1. else latents
-            noise_pred = self.unet(model_inputs, t, encoder_hidden_states=text)
+            if cache is not None:
+                noise_pred = self.unet(model_inputs, t, encoder_hidden_states=text, reuse=dict(mode="record", join=cache["join"]))
+                cache["slots"].append([s.index_select(0, cache["idx"]) for s in self.unet.last_boundary])
+            else:
+                noise_pred = self.unet(model_inputs, t, encoder_hidden_states=text)
             if guidance_scale > 1.:
                 eu, ec = noise_pred.chunk(2, dim=0)
                 noise_pred = ops.cfg_masked(eu.contiguous(), ec.contiguous(), None, guidance_scale)
             latents, _ = self.inv_step(noise_pred, t, latents)
             latents_list.append(latents)
+        self._ref_cache = cache
         if return_intermediates:
             return latents, latents_list
         return latents
+
+    def _take_ref_cache(self, refer_latents, n_act, text, ref_text_rows):
+        """the recorded reference stream of the inversion that produced `refer_latents` (checked by identity: guided step k reads
+        refer_latents[k + 1] = the input of inversion step n - k - 1, model.py:582 vs :883), or None where reuse does not apply:
+        switched off, another inversion, style-align methods (they modulate every block), a modulated block before the join point,
+        or reference rows whose prompt is not the inversion's."""
+        cache, self._ref_cache = self._ref_cache, None
+        if cache is None or not self.reuse_ref_stream or len(cache["slots"]) != n_act or len(refer_latents) != n_act + 1:
+            return None
+        if any(refer_latents[k + 1] is not cache["latents"][n_act - k - 1] for k in range(n_act)):
+            return None
+        for c in (self.unet._ctrls() or []):
+            if c.use_style_align:
+                return None
+        mt = self._min_tca_block()
+        if mt is not None and mt < self.unet.join_block_tb(cache["join"]):
+            return None
+        if any(not torch.equal(text[r], cache["text"][i % cache["text"].shape[0]]) for i, r in enumerate(ref_text_rows)):
+            return None
+        return cache
 
     def _cfg_row_map(self, text, n):
         """CFG batch rows are (latent i mod n, text row i).  Rows whose text embeddings coincide are the same UNet input, bit
@@ -362,6 +404,11 @@ class FreeFinePipeline:
         lat_idx = torch.tensor(lat_rows, device=self.device) if row_map is not None else None
         noises = self._predraw_noise(num_inference_steps - start_step, (2,) + tuple(latents.shape[1:]), eta)
         var_mask = local_var_reg if local_perturbation else torch.ones_like(local_var_reg)
+        # reference-stream reuse: physical rows holding the reference latent (row 1 of the pair) re-enter from the inversion's record
+        n_act = num_inference_steps - start_step
+        ref_flags = tuple(r == 1 for r in lat_rows) if row_map is not None else (False, True, False, True)
+        ref_txt = [txt_rows[p] for p, f in enumerate(ref_flags) if f] if row_map is not None else [1, 3]
+        cache = self._take_ref_cache(refer_latents, n_act, text, ref_txt) if batch_size == 2 else None
         for i, t in enumerate(self.scheduler.timesteps):
             if i < start_step:
                 continue
@@ -374,10 +421,15 @@ class FreeFinePipeline:
                 self.controller.context_guidance = self.linear_param(i, start_step, end_step, num_inference_steps, end_scale=end_scale)
             elif method_type == "mmsa_es" and i >= end_step:
                 self.controller.use_tca = False
+            reuse = None
+            if cache is not None:
+                slot = cache["slots"][n_act - (i - start_step) - 1]
+                nr = sum(ref_flags)
+                reuse = dict(mode="replay", join=cache["join"], ref=ref_flags, state=[s.repeat_interleave(nr, 0) for s in slot] if nr > 1 else slot)
             if row_map is None:
-                noise_pred = self.unet(torch.cat([latents] * 2), t, encoder_hidden_states=text)
+                noise_pred = self.unet(torch.cat([latents] * 2), t, encoder_hidden_states=text, reuse=reuse)
             else:
-                noise_pred = self.unet(latents.index_select(0, lat_idx), t, encoder_hidden_states=text_phys, row_map=row_map)
+                noise_pred = self.unet(latents.index_select(0, lat_idx), t, encoder_hidden_states=text_phys, row_map=row_map, reuse=reuse)
             eu, ec = noise_pred.chunk(2, dim=0)
             noise_pred = ops.cfg_masked(eu.contiguous(), ec.contiguous(), cfg_f, guidance_scale)
             latents = self.ctrl_step(noise_pred, t, latents, var_mask, eta=eta, noise=None if noises is None else noises[i - start_step])[0]
@@ -598,7 +650,8 @@ class FreeFinePipeline:
         source = torch.from_numpy(np.stack(imgs))                       # uint8 [N,H,W,3]; /127.5-1 happens in the VAE's first kernel
         mask = self.prepare_controller_ref_mask(mask, False)
         latents, latents_list = self.invert(source, prompt, guidance_scale=1.0, num_inference_steps=num_step,
-                                            num_actual_inference_steps=num_step - start_step, return_intermediates=True, verbose=verbose)
+                                            num_actual_inference_steps=num_step - start_step, return_intermediates=True, verbose=verbose,
+                                            record_rows=[1] if ref_img is not None else None)      # row 1 = the original image = the guided loop's reference row
         self.controller.reset()
         return mask.detach().cpu().numpy(), latents_list
 
@@ -757,7 +810,8 @@ class FreeFinePipeline:
         for c in ctrls:
             c.reset()
         _, inverted = self.invert(source, "", guidance_scale=1.0, num_inference_steps=num_step,
-                                  num_actual_inference_steps=num_step - start_step, return_intermediates=True)
+                                  num_actual_inference_steps=num_step - start_step, return_intermediates=True,
+                                  record_rows=[2 * i + 1 for i in range(K)])
         for c in ctrls:
             c.reset()
         # ---- per-image masks, controller state, text rows (model.py:1012-1118, 476-526)
@@ -799,6 +853,10 @@ class FreeFinePipeline:
             noises.append(self._predraw_noise(n_act, shape2, eta))
         latents = init.clone()                                # [2K,4,h,w]: rows (edit_i, ref_i)
         lat_v = latents.view(K, 2, *init.shape[1:])
+        ref_flags = tuple(r == 1 for r in lat_rows)
+        cache = self._take_ref_cache(refer, n_act, texts[0], [txt_rows[p] for p, f in enumerate(ref_flags) if f])
+        if cache is not None and any(not torch.equal(t[txt_rows[p]], cache["text"][0]) for t in texts for p, f in enumerate(ref_flags) if f):
+            cache = None
         # like the reference's latents_list (model.py:585-616) the recorded entries ALIAS the live latents: the reference row of
         # entry j is overwritten in place by step j+1's `latents[1:] = ref_latent`
         inter = [[latents[2 * i:2 * i + 2]] for i in range(K)] if return_intermediates else None
@@ -811,7 +869,12 @@ class FreeFinePipeline:
                     c.context_guidance = self.linear_param(i, start_step, end_step, num_step, end_scale=end_scale)
                 elif method_type == "mmsa_es" and i >= end_step:
                     c.use_tca = False
-            eps = self.unet(latents.index_select(0, lat_idx), t, encoder_hidden_states=text_phys, row_map=row_map)
+            reuse = None
+            if cache is not None:        # the reference rows re-enter from the state inversion step n - k - 1 recorded (same latent, timestep, prompt)
+                slot = cache["slots"][n_act - (i - start_step) - 1]
+                nr = sum(ref_flags)
+                reuse = dict(mode="replay", join=cache["join"], ref=ref_flags, state=[s.repeat_interleave(nr, 0) for s in slot] if nr > 1 else slot)
+            eps = self.unet(latents.index_select(0, lat_idx), t, encoder_hidden_states=text_phys, row_map=row_map, reuse=reuse)
             eps = eps.view(K, 4, *init.shape[1:])
             new = torch.empty_like(latents)
             for k in range(K):

@@ -41,6 +41,9 @@ class HipUNet:
         self._row_map = None
         self._plan_cache = {}
         self._row_idx = {}
+        self._reuse, self._reuse_idx, self._enc_a, self.last_boundary = None, {}, {}, None
+        self._in_phase_a = False
+        self.reuse_replays = 0             # forwards whose reference rows re-entered from a recorded state (tests / bench report it)
         self._pack(state)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -136,7 +139,8 @@ class HipUNet:
         self.t_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.cg_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
 
-    _INSTANCE_STATE = ("hook", "controller", "_graphs", "_text_bufs", "use_graph", "_row_map", "_plan_cache", "_row_idx", "t_dev", "cg_dev")
+    _INSTANCE_STATE = ("hook", "controller", "_graphs", "_text_bufs", "use_graph", "_row_map", "_plan_cache", "_row_idx", "t_dev", "cg_dev",
+                       "_reuse", "_reuse_idx", "_enc_a", "last_boundary")
 
     def share(self):
         """a second executor over the SAME packed weights with its own controller hook, device scalars, static buffers and
@@ -145,6 +149,7 @@ class HipUNet:
         other.__dict__.update({k: v for k, v in self.__dict__.items() if k not in self._INSTANCE_STATE})
         other.hook, other.controller = "edit", None
         other._graphs, other._text_bufs, other._plan_cache, other._row_idx = {}, {}, {}, {}
+        other._reuse, other._reuse_idx, other._enc_a, other.last_boundary = None, {}, {}, None
         other.use_graph, other._row_map = self.use_graph, None
         other.t_dev, other.cg_dev = torch.zeros_like(self.t_dev), torch.zeros_like(self.cg_dev)
         return other
@@ -166,8 +171,8 @@ class HipUNet:
     def to(self, *a, **k):
         return self
 
-    def __call__(self, sample, timestep, encoder_hidden_states=None, row_map=None, **kw):
-        return self.forward(sample, timestep, encoder_hidden_states, row_map)
+    def __call__(self, sample, timestep, encoder_hidden_states=None, row_map=None, reuse=None, **kw):
+        return self.forward(sample, timestep, encoder_hidden_states, row_map, reuse)
 
     # ------------------------------------------------------------------------------------------------------------
     # text-side precompute: cross-attention K and V^T for all 16 blocks (constant across the sampling loop)
@@ -195,14 +200,42 @@ class HipUNet:
     # ------------------------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------------------------
-    def forward(self, sample, timestep, enc, row_map=None):
+    # ------------------------------------------------------------------------------------------------------------
+    # reference-stream reuse ("stored reference K/V"): the guided loop's reference row UNet(x_ref, t_i, "") is the very
+    # (latent, timestep, prompt) the inversion pass evaluated as its original-image row (model.py:582-586 vs :883), and nothing
+    # modulates that row before the first TCA block (layer_idx starts at transformer block 10 = the first of up_blocks[2]; its cross
+    # attention is plain, attention.py:1381-1383).  So the inversion forward RECORDS that row's state at the join point -- the hidden
+    # state entering the up block that holds the first TCA layer and the skip tensors still to be consumed -- and the guided forward
+    # REPLAYS it: conv_in ... up_blocks[join-1] run on the edit rows only, the reference row joins from the recorded state for
+    # the remaining up blocks (where its K / V feed the edit rows).  Exact in exact arithmetic, like the CFG row de-duplication.
+    # ------------------------------------------------------------------------------------------------------------
+    def join_block(self, min_tca_block=None):
+        """the up block at whose entrance the reference row may join: the last one whose first transformer block is <= the first
+        modulated self-attention block (None = no modulated block: the last up block)"""
+        n = len(self.up)
+        tb = len([t for blk in self.down if blk.attn for t in blk.attn]) + 1
+        first = []
+        for blk in self.up:
+            first.append(tb)
+            tb += len(blk.attn) if blk.attn else 0
+        if min_tca_block is None:
+            return n - 1, first[n - 1]
+        j = max([i for i in range(n) if first[i] <= min_tca_block], default=0)
+        return j, first[j]
+
+    def forward(self, sample, timestep, enc, row_map=None, reuse=None):
         """sample [B,Cin,h,w] fp32 (cuda), timestep int/0-d tensor, enc [Bt,77,D] -> eps [B,Cout,h,w] fp32.
         row_map (optional): the caller's LOGICAL batch has len(row_map) rows of which only the distinct ones were passed in
         (`sample`/`enc` hold the physical rows, row_map[logical] = physical): the attention controller still plans for the
-        logical batch, its pass tables are translated, and the result is expanded back to the logical batch."""
+        logical batch, its pass tables are translated, and the result is expanded back to the logical batch.
+        reuse (optional, see above): dict(mode="record", join=j) -> after the call `self.last_boundary` holds the tensors at the
+        entrance of up block j ([x, skip, skip, ...], all physical rows); dict(mode="replay", join=j, ref=[bool per physical row
+        of ONE image], state=[tensors [n_ref_rows, HW, C] ...]) -> rows flagged `ref` skip everything before up block j and
+        continue from `state` (their eps rows are still produced: the remaining blocks run on all rows)."""
         sample = sample.to(self.device, torch.float32).contiguous()
         B = sample.shape[0]
         self._row_map = tuple(row_map) if row_map is not None else None
+        self._reuse = self._prepare_reuse(reuse, B, enc)
         self.t_dev.fill_(float(timestep))
         ctrls = self._ctrls()
         assert not ctrls or B % len(ctrls) == 0, f"batch {B} is not a multiple of the {len(ctrls)} batched images"
@@ -210,21 +243,67 @@ class HipUNet:
             assert all(c.context_guidance == ctrls[0].context_guidance for c in ctrls), "batched images share one schedule"
             self.cg_dev.fill_(float(ctrls[0].context_guidance))
         text_kv = self.prepare_text(enc)
+        ru = self._reuse
+        if ru is not None and ru["mode"] == "replay":
+            ru["text_kv_a"] = self.prepare_text(ru["enc_a"])
+            self.reuse_replays += 1
         if not self.use_graph:
             return self._expand(self._run(sample, text_kv))
         # graph mode: plan every attention call first (this also refreshes the controller's static mask vectors and
         # advances its counters exactly as an eager forward would); the plans' fingerprint is part of the graph key
         state = [(c.cur_att_layer, c.cur_step) for c in ctrls]
         fp = self._plan_all(B, sample.shape[2], sample.shape[3])
-        sig = (B, tuple(sample.shape), tuple(enc.shape), fp, self._row_map, len(ctrls))
+        rsig = None if ru is None else (ru["mode"], ru["join"], ru.get("ref"), tuple(tuple(t.shape) for t in ru.get("state", ())))
+        sig = (B, tuple(sample.shape), tuple(enc.shape), fp, self._row_map, len(ctrls), rsig)
         g = self._graphs.get(sig)
         if g is None:
             for c, st in zip(ctrls, state):
                 c.cur_att_layer, c.cur_step = st
             g = self._capture(sample, text_kv, sig)
         g["x"].copy_(sample)
+        if ru is not None and ru["mode"] == "replay":      # the recorded reference state of THIS step into the graph's static inputs
+            for dst, src in zip(g["ref_in"], ru["state"]):
+                dst.copy_(src)
         g["graph"].replay()
+        if ru is not None and ru["mode"] == "record":
+            self.last_boundary = g["boundary"]
         return self._expand(g["out"].clone())
+
+    def _prepare_reuse(self, reuse, B, enc):
+        if reuse is None:
+            return None
+        ru = dict(reuse)
+        K = max(1, len(self._ctrls()))
+        Bp = B // K
+        if ru["mode"] == "replay":
+            ref = tuple(bool(r) for r in ru["ref"])
+            assert len(ref) == Bp and any(ref) and not all(ref), (ref, Bp)
+            ru["ref"] = ref
+            ru["sel"] = [p for p in range(Bp) if not ref[p]]                 # physical rows (of one image) that run the whole net
+            key = (B, ref)
+            ent = self._reuse_idx.get(key)
+            if ent is None:
+                sel, nr = ru["sel"], sum(ref)
+                idx_a = [i * Bp + p for i in range(K) for p in sel]
+                # rows of cat([phase-A rows (image-major), recorded reference rows (image-major)]) in physical order
+                perm, ra, rr = [], 0, 0
+                for i in range(K):
+                    a0, r0, ia, ir = i * len(sel), K * len(sel) + i * nr, 0, 0
+                    for p in range(Bp):
+                        if ref[p]:
+                            perm.append(r0 + ir); ir += 1
+                        else:
+                            perm.append(a0 + ia); ia += 1
+                ent = self._reuse_idx[key] = (torch.tensor(idx_a, device=self.device), torch.tensor(perm, device=self.device))
+            ru["idx_a"], ru["perm"] = ent
+            ck = (id(enc), enc._version, key)
+            ea = self._enc_a.get(ck)
+            if ea is None or ea[0]() is not enc:
+                if len(self._enc_a) > 8:
+                    self._enc_a.clear()
+                ea = self._enc_a[ck] = (weakref.ref(enc), enc.to(self.device).index_select(0, ru["idx_a"]).contiguous())
+            ru["enc_a"] = ea[1]
+        return ru
 
     def _expand(self, eps):
         if self._row_map is None:
@@ -236,34 +315,52 @@ class HipUNet:
             idx = self._row_idx[(rm, K)] = torch.tensor([i * Bp + r for i in range(K) for r in rm], device=self.device)
         return eps.index_select(0, idx)
 
-    def _plan_one(self, c, is_cross, place, B, S, heads):
-        """one controller's plan for its logical batch, translated to its physical (deduplicated) rows"""
+    def _plan_one(self, c, is_cross, place, B, S, heads, sel=None):
+        """one controller's plan for its logical batch, translated to its physical (deduplicated) rows.  B = physical rows of
+        the image; sel (reference-stream reuse, phase A) = the subset of them present in this launch, in launch order."""
         rm = self._row_map
         plan = c.plan(self.hook, is_cross, place, len(rm) if rm is not None else B, S, heads, self.device)
-        if rm is None or plan["passes"] is None:
+        if plan["passes"] is None or (rm is None and sel is None):
             return plan
-        rep = [rm.index(pr) for pr in range(B)]            # representative logical row of every physical row
+        rmx = rm if rm is not None else tuple(range(B))
+        rep = [rmx.index(pr) for pr in range(B)]           # representative logical row of every physical row
         plan = dict(plan)
-        plan["passes"] = [[None if rows[l] is None else rows[l].remap(rm, l) for l in rep] for rows in plan["passes"]]
+        plan["passes"] = [[None if rows[l] is None else rows[l].remap(rmx, l) for l in rep] for rows in plan["passes"]]
         if "ref_rows" in plan:
-            plan["ref_rows"] = [rm[plan["ref_rows"][l]] for l in rep]
+            assert sel is None, "shared-K/V (style-align) attention cannot run on a row subset"
+            plan["ref_rows"] = [rmx[plan["ref_rows"][l]] for l in rep]
+        if sel is not None:
+            ren = {p: a for a, p in enumerate(sel)}
+            plan["passes"] = [[None if rows[p] is None else rows[p].renumber(ren) for p in sel] for rows in plan["passes"]]
         return plan
+
+    def _phase(self, B):
+        """(physical rows per image in the CURRENT launch, subset of the image's physical rows or None) -- phase A of a replayed
+        forward holds only the non-reference rows"""
+        K = max(1, len(self._ctrls()))
+        ru = self._reuse
+        if ru is not None and ru["mode"] == "replay" and self._in_phase_a:
+            return len(ru["ref"]), ru["sel"]
+        return B // K, None
 
     def _plan(self, is_cross, place, B, S, heads):
         """plan of this attention call for the whole physical batch.  Image-batched forwards: every image's controller plans
         its own Bp rows; the tables are concatenated with the image's row offset, the tiled-head rule pinned to the row index
         the image would have had alone (attention.py:859 vs 761 depend on b*heads+head)."""
         ctrls = self._ctrls()
+        Bp, sel = self._phase(B)
         if len(ctrls) == 1:
-            return self._plan_one(ctrls[0], is_cross, place, B, S, heads)
+            return self._plan_one(ctrls[0], is_cross, place, Bp, S, heads, sel)
         K = len(ctrls)
-        Bp = B // K
-        plans = [self._plan_one(c, is_cross, place, Bp, S, heads) for c in ctrls]
+        plans = [self._plan_one(c, is_cross, place, Bp, S, heads, sel) for c in ctrls]
         if all(p["passes"] is None for p in plans):
             return plans[0]
         assert len({p["kind"] for p in plans}) == 1, "batched images must take the same attention branch kind"
         rm = self._row_map
         rep = [rm.index(pr) for pr in range(Bp)] if rm is not None else list(range(Bp))
+        if sel is not None:
+            rep = [rep[p] for p in sel]
+        Bp = len(rep)                                          # rows per image in this launch
         npass = max(len(p["passes"]) for p in plans if p["passes"] is not None)
         merged = [[] for _ in range(npass)]
         for i, plan in enumerate(plans):
@@ -299,7 +396,8 @@ class HipUNet:
 
     def _ctrl_key(self, B, H, W):
         """everything a forward's attention plans depend on (masks by identity + in-place version)"""
-        key = [self.hook, B, H, W, self._row_map]
+        ru = self._reuse
+        key = [self.hook, B, H, W, self._row_map, None if ru is None or ru["mode"] != "replay" else (ru["join"], ru["ref"])]
         for c in self._ctrls():
             mv = tuple((m.data_ptr(), m._version) if torch.is_tensor(m) else None
                        for m in (c.fg_retain_mask, c.fg_ref_mask, c.local_edit_region, c.src_masks, c.tgt_masks))
@@ -328,7 +426,10 @@ class HipUNet:
 
     def _plan_all_slow(self, B, H, W):
         fps = []
-        for is_cross, place, S, heads in self._call_list(H, W):
+        ru = self._reuse
+        join_tb = self.join_block_tb(ru["join"]) if (ru is not None and ru["mode"] == "replay") else -1
+        for ci, (is_cross, place, S, heads) in enumerate(self._call_list(H, W)):
+            self._in_phase_a = ci // 2 < join_tb             # phase A of a replayed forward: the non-reference rows only
             plan = self._plan(is_cross, place, B, S, heads)
             if plan["passes"] is None:
                 fps.append(0)
@@ -338,12 +439,25 @@ class HipUNet:
                                                        0 if e.kmask is None else e.kmask.data_ptr(),
                                                        0 if e.qsel is None else e.qsel.data_ptr()) for e in r) for r in plan["passes"])
             fps.append((plan["kind"], plan["needs_cg"], rows))
+        self._in_phase_a = False
         return (self.hook, tuple(fps))
+
+    def join_block_tb(self, join):
+        """index of the first transformer block of up block `join` (attention calls 2 * that and later belong to phase B)"""
+        tb = len([t for blk in self.down if blk.attn for t in blk.attn]) + 1
+        for blk in self.up[:join]:
+            tb += len(blk.attn) if blk.attn else 0
+        return tb
 
     def _capture(self, sample, text_kv, sig):
         ctrls = self._ctrls()
         state = [(c.cur_att_layer, c.cur_step) for c in ctrls]
         x_static = sample.clone()
+        ru = self._reuse
+        ref_in = None
+        if ru is not None and ru["mode"] == "replay":          # static inputs for the recorded reference state (refilled before every replay)
+            ref_in = [t.clone() for t in ru["state"]]
+            ru["state_run"] = ref_in
         # warm-up outside capture (lazy module loading, LDS opt-ins, first upload of mask vectors), counters restored after
         self._run(x_static, text_kv)
         for c, st in zip(ctrls, state):
@@ -352,7 +466,9 @@ class HipUNet:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = self._run(x_static, text_kv)
-        g = dict(graph=graph, x=x_static, out=out)
+        g = dict(graph=graph, x=x_static, out=out, ref_in=ref_in, boundary=self.last_boundary if (ru is not None and ru["mode"] == "record") else None)
+        if ru is not None:
+            ru.pop("state_run", None)
         self._graphs[sig] = g
         return g
 
@@ -411,12 +527,23 @@ class HipUNet:
         cfg = self.cfg
         B, _, H, W = sample.shape
         dt = self.dtype
+        ru = self._reuse
+        replay = ru is not None and ru["mode"] == "replay"
+        record = ru is not None and ru["mode"] == "record"
+        BB = B                                                # rows of the whole launch (phase B)
+        if replay:                                            # phase A: everything before up block `join` on the non-reference rows
+            sample = sample.index_select(0, ru["idx_a"])
+            B = sample.shape[0]
+            text_kv = list(ru["text_kv_a"][:self.join_block_tb(ru["join"])]) + list(text_kv[self.join_block_tb(ru["join"]):])
+        self._in_phase_a = replay
         ti = iter(text_kv)
         # time embedding -> silu(emb) -> all 22 resnet projections in one GEMM (fp32 row biases)
-        te = ops.timestep_embed(self.t_dev, self.freq, B, dt, flip=cfg.flip_sin_to_cos)
+        te = ops.timestep_embed(self.t_dev, self.freq, BB, dt, flip=cfg.flip_sin_to_cos)      # (every row carries the same timestep)
         e1 = ops.linear(te, self.te1[0], self.te1[1], K=self.te1[2], silu=True)
         e2 = ops.linear(e1, self.te2[0], self.te2[1], K=self.te2[2], silu=True)     # = silu(time_embedding(t_emb))
         temb_all = ops.linear(e2, self.temb_w, self.temb_b, K=self.te2[0].shape[0], out_f32=True)
+        temb_full = temb_all
+        temb_all = temb_all[:B]
         x = ops.pack_nchw(sample, list(range(B)), self.cin_pad, dt)
         x = ops.conv3x3(x, self.conv_in[0], self.conv_in[1], B, H, W, self.cin_pad)
         skips = [(x, H, W)]
@@ -440,6 +567,17 @@ class HipUNet:
             return ops.cat_dst((B, HW), C1, skips[-1][0].shape[-1], dt, x.device) if skips else None
         x = self._resblock(self.mid.res[1], x, B, H, W, temb_all, out=cat_dst(self.mid.res[1].cout, H * W))
         for i, blk in enumerate(self.up):
+            if ru is not None and i == ru["join"]:
+                if record:                                    # the state every row enters up block `join` with: [x, skips still to be consumed (top of stack first)]
+                    self.last_boundary = [x] + [s for s, _, _ in reversed(skips)]
+                if replay:                                    # the reference rows join: recorded state + phase-A rows -> physical row order
+                    state = ru.get("state_run") or ru["state"]
+                    assert len(state) == 1 + len(skips), (len(state), len(skips))
+                    merge = lambda a, r: torch.cat([a, r.to(a.dtype)], 0).index_select(0, ru["perm"])
+                    x = merge(x, state[0])
+                    skips = [(merge(s, st), sh, sw) for (s, sh, sw), st in zip(skips, reversed(state[1:]))]
+                    B, temb_all = BB, temb_full
+                    self._in_phase_a = False
             for j, r in enumerate(blk.res):
                 s, sh, sw = skips.pop()
                 assert (sh, sw) == (H, W)

@@ -334,3 +334,47 @@ def test_vae_full_size_vs_oracle(gpu):
         assert e_enc < tol and e_dec < 2 * tol
         del hv
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_reference_stream_reuse_is_exact(gpu, graph):
+    """Reference-stream reuse (the guided loop's reference row re-enters the UNet at the first TCA block from the state the inversion
+    recorded for the same latent / timestep / prompt) against the plain recomputation and against the REFERENCE's golden trajectory:
+    single-image edits (3 physical rows with a prompt, 2 with an empty one, 4 without row de-duplication) and the image-batched path.
+    fp32: the two ways agree to summation-order level; the forwards counted in `reuse_replays` prove the reuse path ran."""
+    g = np.load(os.path.join(GOLD, "g5_loops.npz"))
+    ori_img, coarse, _ = synth_images()
+    ori, tgt, *_ = mask_inputs()
+    for name, unet_name, kw in edit_cases():
+        if name not in ("edit_tca_draw", "edit_tca_auto", "edit_mmsa_es"):
+            continue
+        kw = dict(kw)
+        text, gs, eta = kw.pop("guidance_text"), kw.pop("guidance_scale"), kw.pop("eta")
+        n_guided = kw["num_step"] - kw["start_step"]
+        trajs = {}
+        for reuse, dedup in ((True, True), (False, True), (True, False)):
+            model = make_pipe(gpu, unet_name, "edit", graph=graph)
+            model.reuse_ref_stream, model.dedup_rows = reuse, dedup
+            model.FreeFine_generation(ori_img, ori, coarse, tgt, text, gs, eta, verbose=True, seed=42, return_intermediates=True, **kw)
+            assert model.unet.reuse_replays == (n_guided if reuse else 0), (name, reuse, dedup, model.unet.reuse_replays)
+            trajs[(reuse, dedup)] = [t.clone() for t in model.last_intermediates]
+            dev = traj_dev(model.last_intermediates, g[f"{name}_traj"])
+            print(f"{name} graph={graph} reuse={reuse} dedup={dedup}: latent L-inf vs reference golden {dev:.2e}")
+            assert dev < TOL
+        assert traj_dev(trajs[(True, True)], [t.cpu().numpy() for t in trajs[(False, True)]]) < 1e-4
+    # image-batched edits: reuse on vs off
+    name, unet_name, kw = edit_cases()[0]
+    kw = {k: v for k, v in kw.items() if k in ("end_step", "num_step", "start_step", "method_type", "end_scale")}
+    cases, seeds = _batch_cases(), [42, 7, 1234]
+    outs = {}
+    for reuse in (True, False):
+        model = make_pipe(gpu, unet_name, "edit", graph=graph)
+        model.reuse_ref_stream = reuse
+        for sel in ([0, 1], [0, 1, 2]):
+            model.FreeFine_generation_batch([cases[i] for i in sel], 7.5, 1.0, seeds=[seeds[i] for i in sel], return_intermediates=True, **kw)
+            outs[(reuse, tuple(sel))] = [[t.clone() for t in tr] for tr in model.last_intermediates]
+        assert (model.unet.reuse_replays > 0) == reuse
+    for sel in ((0, 1), (0, 1, 2)):
+        for j in range(len(sel)):
+            assert traj_dev(outs[(True, sel)][j], [t.cpu().numpy() for t in outs[(False, sel)][j]]) < 1e-4, (sel, j)
+    assert traj_dev(outs[(True, (0, 1))][0], g[f"{name}_traj"]) < TOL
