@@ -36,6 +36,7 @@ F_UNET = 0.804e12      # algorithmic FLOPs, one sample, one UNet forward @64x64 
 F_TCA = 72.5e9         # one extra attention pass in blocks 10-15 per sample-forward
 F_VAE = 7.26e12        # 2 encodes + 2 decodes @512^2
 F_VAE_ENC, F_VAE_DEC = 1.117e12, 2.515e12
+F_UNET_PHASE_A = 0.4396e12   # conv_in + down blocks + mid block + up_blocks[0..1] of one sample-forward (FlopCounterMode on the oracle UNet)
 
 
 def synth_inputs(idx=0):
@@ -354,7 +355,10 @@ def main():
         # executed FLOPs: the exact (math-preserving) reductions that are ON lower what runs, not what the algorithm needs -- row
         # de-duplication (3 of the 4 guided rows are physical), decode of the edited latent only in the batched path
         rows_g = 3 if model.dedup_rows else 4
-        f_exec = n * ((2 + rows_g) * F_UNET + rows_g * F_TCA) + 2 * F_VAE_ENC + (1 if args.batch > 1 else 2) * F_VAE_DEC
+        # reference-stream reuse: each reference row skips conv_in ... up_blocks[1] (439.6 of the 804.3 GFLOP of a sample-forward)
+        reuse_on = bool(getattr(model, "reuse_ref_stream", False)) and model.unet.reuse_replays > 0
+        skipped = (rows_g - 2) * F_UNET_PHASE_A if reuse_on else 0.0
+        f_exec = n * ((2 + rows_g) * F_UNET - skipped + rows_g * F_TCA) + 2 * F_VAE_ENC + (1 if args.batch > 1 else 2) * F_VAE_DEC
         value = world * args.steps * args.concurrent * args.batch / dt
         line = {
             "metric": "edited images/sec/GPU @512px 50-step DDIM", "value": round(value, 4), "unit": "images/s", "n_gpus": world,
@@ -367,6 +371,8 @@ def main():
                        "images_per_gpu_per_step": args.concurrent * args.batch, "concurrent_streams": args.concurrent,
                        "images_per_unet_batch": args.batch, "unet_batch": 4 * args.batch, "hip_graph": not args.no_graph,
                        "exact_row_dedup": model.dedup_rows and "on: the duplicated reference row of the CFG batch is evaluated once (3 physical rows), outputs unchanged",
+                       "reference_stream_reuse": ("on: the guided loop's reference row re-enters at up_blocks[2] from the state the inversion pass recorded for the "
+                                                  "same (latent, timestep, prompt); outputs unchanged") if reuse_on else "off",
                        "vae_decode": "batched path decodes the edited latent only (the reference decodes the reference stream too and drops it unless return_ori)" if args.batch > 1 else "both streams, like the reference",
                        "algorithmic_tflop_per_image": round(f_img / 1e12, 1),
                        "whole_path_tflops_per_gpu": round(f_img * value / world / 1e12, 1),

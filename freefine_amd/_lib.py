@@ -9,9 +9,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FREEFINE_HIP_LIB") or os.path.join(_HERE, "libfreefine_hip.so")   # env override: A/B builds of the same ABI
 
 FFN_F32, FFN_BF16, FFN_BF16X3 = 0, 1, 2
-IG_OUT_SILU, IG_OUT_F32, IG_GEGLU, IG_OUT_TRANSPOSED = 1, 2, 4, 8
+IG_OUT_SILU, IG_OUT_F32, IG_GEGLU, IG_OUT_TRANSPOSED, IG_OUT_PAIR = 1, 2, 4, 8, 16
 ATT_MAXP, ATT_MAXB = 4, 16
 ATT_HEAD_RULE, ATT_UNIFORM_SEL1, ATT_UNIFORM_SEL0 = 1, 2, 4
+NORM_SILU, NORM_OUT_PAIR = 1, 2
 
 
 class IgemmDesc(C.Structure):
@@ -43,7 +44,7 @@ class AttnDesc(C.Structure):
         ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("out", C.c_void_p), ("w_dev", C.c_void_p),
         ("Bo", C.c_int), ("S", C.c_int), ("Sk", C.c_int), ("heads", C.c_int), ("D", C.c_int),
         ("ldq", C.c_int), ("ldk", C.c_int), ("ldvt", C.c_int), ("ldo", C.c_int),
-        ("scale", C.c_float), ("npass", C.c_int),
+        ("scale", C.c_float), ("npass", C.c_int), ("out_pair", C.c_int), ("reserved", C.c_int),
         ("e", AttnEntry * (ATT_MAXP * ATT_MAXB)),
     ]
 
@@ -93,6 +94,7 @@ SYMBOLS = {
     "ffn_gn_apply": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "ffn_groupnorm": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "ffn_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f]),
+    "ffn_layernorm_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f]),
     "ffn_softmax_rows": (_i, [_vp, _i, _vp, _vp, _l, _i, _f]),
     "ffn_cfg_masked": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _l, _i]),
     "ffn_ddim_inv_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _l]),

@@ -12,6 +12,7 @@
 // fp32 kernel.
 #pragma once
 #include "attention.h"
+#include "igemm.h"
 
 __device__ __forceinline__ void x3_split8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
     hi[0] = pack_bf16x2(a[0], a[1]);
@@ -56,6 +57,11 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const AttnParams p) {
         const AttnEntry& e0 = p.e[pass * ATT_MAXB + b];
         nactive += (e0.w_const != 0.f || e0.w_slope != 0.f) ? 1 : 0;
     }
+    // output row q of batch row b, columns head * D + d .. + 3: fp32, or (out_pair) the bf16 pair form hi | lo at ldo / 2
+    auto store_out = [&](int q, int d, const float* vv) {
+        if (p.out_pair) store_pair_row4(reinterpret_cast<bf16*>(p.out) + ((long)b * p.S + q) * p.ldo + head * D + d, p.ldo / 2, vv);
+        else store4(Og + ((long)b * p.S + q) * p.ldo + head * D + d, vv);
+    };
     if (nactive == 0) {
 #pragma unroll
         for (int f = 0; f < QF; ++f) {
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const AttnParams p) {
             for (int i = 0; i < FD; ++i) {
                 const int d = i * 16 + 4 * g;
                 float z[4] = {0.f, 0.f, 0.f, 0.f};
-                if (q < p.S && d < D) store4(Og + ((long)b * p.S + q) * p.ldo + head * D + d, z);
+                if (q < p.S && d < D) store_out(q, d, z);
             }
         }
         return;
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const AttnParams p) {
                 } else {
                     const int d = i * 16 + 4 * g;
                     float vv[4] = {v[0], v[1], v[2], v[3]};
-                    if (q < p.S && d < D) store4(Og + ((long)b * p.S + q) * p.ldo + head * D + d, vv);
+                    if (q < p.S && d < D) store_out(q, d, vv);
                 }
             }
         }

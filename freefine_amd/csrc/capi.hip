@@ -264,7 +264,8 @@ static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn, int splitk = 1) {
     if (splitk > 1) {       // split-K: raw fp32 slabs + igemm_splitk_reduce_kernel (which applies every plain epilogue option)
         if (!can_split(d) || (d.K / 64) % splitk != 0 || d.K / 64 / splitk < 2 || (long)splitk * d.M * d.N * 4 > d.ws_bytes || (long)splitk * d.M * d.N * 4 >= lim) return false;
     } else {
-        if (d.alpha != 1.0f || (d.flags & ~(FFN_IG_GEGLU | (d.x3 ? FFN_IG_OUT_F32 : 0)))) return false;
+        if (d.alpha != 1.0f || (d.flags & ~(FFN_IG_GEGLU | (d.x3 ? (FFN_IG_OUT_F32 | FFN_IG_OUT_PAIR) : 0)))) return false;
+        if (d.x3 && ((d.flags & FFN_IG_GEGLU) != 0) != ((d.flags & FFN_IG_OUT_PAIR) != 0)) return false;      // the split-bf16 GEGLU tile writes the pair form, nothing else does
         if ((d.flags & FFN_IG_GEGLU) && bn != 256) return false;
         if (d.rowbias && d.rows_per_batch < 128) return false;      // a wave's rows (bm / 2) may straddle two images, not three
     }
@@ -280,7 +281,7 @@ static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn, int splitk = 1) {
         a_bytes = (long)d.M * d.lda * 2;
         if (a_bytes + 256l * d.lda * 2 >= lim) return false;
     }
-    if ((long)d.N * d.Kpad * 2 >= lim || (long)(d.M + 256) * d.ldo * osz >= lim) return false;
+    if ((long)d.N * d.Kpad * 2 >= lim || (long)(d.M + 256) * d.ldo * ((d.flags & FFN_IG_OUT_PAIR) ? 2 : osz) >= lim) return false;
     if (d.residual && (long)(d.M + 256) * d.ldr * osz >= lim) return false;
     return true;
 }
@@ -859,6 +860,10 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
     } else {
         REQUIRE(d->N % 4 == 0 && d->ldo % 4 == 0, "igemm: N=%d and ldo=%d must be multiples of 4", d->N, d->ldo);
         if (d->residual) REQUIRE(d->ldr % 4 == 0, "igemm: ldr=%d must be a multiple of 4", d->ldr);
+        if (d->flags & FFN_IG_OUT_PAIR) {
+            const int nout = (d->flags & FFN_IG_GEGLU) ? d->N / 2 : d->N;
+            REQUIRE(dtype == FFN_BF16X3 && !d->residual && d->ldo % 16 == 0 && d->ldo / 2 >= nout, "igemm: pair output needs FFN_BF16X3, no residual, ldo %% 16 == 0, ldo/2 >= columns");
+        }
         if (d->flags & FFN_IG_GEGLU) {
             REQUIRE(d->N % 64 == 0, "igemm: GEGLU needs N %% 64 == 0 (N=%d)", d->N);
             REQUIRE(!d->residual && !d->rowbias && !(d->flags & (FFN_IG_OUT_F32 | FFN_IG_OUT_SILU)), "igemm: GEGLU epilogue is exclusive");
@@ -1005,6 +1010,7 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
     REQUIRE(d->D % epc == 0, "attn: D=%d must be a multiple of %d", d->D, epc);
     REQUIRE(d->ldq % epc == 0 && d->ldk % epc == 0 && d->ldvt % epc == 0 && d->ldo % 4 == 0, "attn: leading dims must be chunk aligned");
     REQUIRE(d->ldvt >= d->Sk, "attn: ldvt=%d < Sk=%d", d->ldvt, d->Sk);
+    if (d->out_pair) REQUIRE(dtype == FFN_BF16X3 && d->D <= 64 && d->ldo % 16 == 0 && d->ldo / 2 >= d->heads * d->D, "attn: pair output needs FFN_BF16X3, D <= 64, ldo %% 16 == 0");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int D = d->D;
     if (dtype == FFN_BF16X3 && D <= 64) {      // split-bf16 arithmetic on fp32 operands (attention_x3.h); other head sizes: the exact fp32 kernel
@@ -1078,6 +1084,15 @@ extern "C" int ffn_groupnorm(void* stream, int dtype, const void* x, void* y, co
     const long slice = (long)HW * (C / G);
     (void)slice;
     const bool fused = ffn_gn_fused(B, HW, C, G) != 0;
+    const bool pair = silu & FFN_NORM_OUT_PAIR;
+    REQUIRE(!pair || (dtype == FFN_F32 && C % 4 == 0), "groupnorm: pair output needs fp32 input and C %% 4 == 0");
+    silu &= FFN_NORM_SILU;
+    if (fused && pair) {
+        dim3 grid(G, B);
+        if (silu) LAUNCH((gn_fused_kernel<float, true, true>), grid, dim3(1024), 0, s, (const float*)x, (float*)y, gamma, beta, HW, C, G, eps);
+        else LAUNCH((gn_fused_kernel<float, false, true>), grid, dim3(1024), 0, s, (const float*)x, (float*)y, gamma, beta, HW, C, G, eps);
+        return check_launch("gn_fused(pair)");
+    }
     if (fused) {   // one workgroup owns a whole (batch, group) slice: statistics + normalise + SiLU in ONE launch
                                            // (measured: wins up to 32x32 latents; at 64x64 the 20-60 byte per-pixel group segments coalesce badly)
         dim3 grid(G, B);
@@ -1093,7 +1108,7 @@ extern "C" int ffn_groupnorm(void* stream, int dtype, const void* x, void* y, co
     REQUIRE(partial_ws && scale && shift, "groupnorm: workspace required beyond 32x32 positions");
     int rc = ffn_gn_stats(stream, dtype, x, gamma, beta, B, HW, C, G, eps, partial_ws, scale, shift);
     if (rc) return rc;
-    return ffn_gn_apply(stream, dtype, x, y, scale, shift, B, HW, C, silu);
+    return ffn_gn_apply(stream, dtype, x, y, scale, shift, B, HW, C, silu | (pair ? FFN_NORM_OUT_PAIR : 0));
 }
 extern "C" int ffn_gn_stats(void* stream, int dtype, const void* x, const float* gamma, const float* beta, int B, int HW, int C,
                             int G, float eps, float* partial_ws, float* scale, float* shift) {
@@ -1123,6 +1138,12 @@ extern "C" int ffn_gn_apply(void* stream, int dtype, const void* x, void* y, con
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long nch = (long)B * HW * (C / epc);
     const int grid = grid_for(nch);
+    if (silu & FFN_NORM_OUT_PAIR) {
+        REQUIRE(dtype == FFN_F32, "gn_apply: pair output needs fp32 input");
+        if (silu & FFN_NORM_SILU) LAUNCH((gn_apply_kernel<float, true, true>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, nch, HW, C);
+        else LAUNCH((gn_apply_kernel<float, false, true>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, nch, HW, C);
+        return check_launch("gn_apply(pair)");
+    }
     if (dtype == FFN_F32) {
         if (silu) LAUNCH((gn_apply_kernel<float, true>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, nch, HW, C);
         else LAUNCH((gn_apply_kernel<float, false>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, nch, HW, C);
@@ -1149,6 +1170,16 @@ extern "C" int ffn_layernorm(void* stream, int dtype, const void* x, void* y, co
         else LAUNCH((layernorm_kernel<bf16, 6>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, gamma, beta, M, C, eps);
     }
     return check_launch("layernorm");
+}
+extern "C" int ffn_layernorm_pair(void* stream, const float* x, void* y, const float* gamma, const float* beta, int M, int C, float eps) {
+    REQUIRE(x && y && gamma && beta && C % 4 == 0 && aligned16(x) && aligned16(y), "layernorm_pair: bad arguments");
+    const int cch = C / 4;
+    REQUIRE(cch <= 64 * 6, "layernorm_pair: C=%d too large", C);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int grid = (M + 3) / 4;
+    if (cch <= 128) LAUNCH((layernorm_kernel<float, 2, true>), dim3(grid), dim3(256), 0, s, x, (float*)y, gamma, beta, M, C, eps);
+    else LAUNCH((layernorm_kernel<float, 6, true>), dim3(grid), dim3(256), 0, s, x, (float*)y, gamma, beta, M, C, eps);
+    return check_launch("layernorm(pair)");
 }
 extern "C" int ffn_softmax_rows(void* stream, int dtype, const void* x, void* y, long M, int N, float scale) {
     REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "softmax_rows: bad dtype");

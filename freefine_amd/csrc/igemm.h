@@ -22,7 +22,17 @@
 #include "../../include/freefine_hip.h"
 
 enum { AMODE_DENSE = 0, AMODE_CONV3 = 1 };
-enum { IG_OUT_SILU = FFN_IG_OUT_SILU, IG_OUT_F32 = FFN_IG_OUT_F32, IG_GEGLU = FFN_IG_GEGLU, IG_OUT_TRANSPOSED = FFN_IG_OUT_TRANSPOSED };
+enum { IG_OUT_SILU = FFN_IG_OUT_SILU, IG_OUT_F32 = FFN_IG_OUT_F32, IG_GEGLU = FFN_IG_GEGLU, IG_OUT_TRANSPOSED = FFN_IG_OUT_TRANSPOSED, IG_OUT_PAIR = FFN_IG_OUT_PAIR };
+// four fp32 values -> the bf16 pair form (hi at p, lo at p + lo_off), 8 bytes each
+__device__ __forceinline__ void store_pair_row4(bf16* p, int lo_off, const float* v) {
+    u32x2 hi, lo;
+    hi[0] = pack_bf16x2(v[0], v[1]);
+    hi[1] = pack_bf16x2(v[2], v[3]);
+    lo[0] = pack_bf16x2(v[0] - __uint_as_float(hi[0] << 16), v[1] - __uint_as_float(hi[0] & 0xffff0000u));
+    lo[1] = pack_bf16x2(v[2] - __uint_as_float(hi[1] << 16), v[3] - __uint_as_float(hi[1] & 0xffff0000u));
+    *reinterpret_cast<u32x2*>(p) = hi;
+    *reinterpret_cast<u32x2*>(p + lo_off) = lo;
+}
 typedef ffn_igemm_desc IgemmParams;
 
 // epilogue shared by the igemm kernels: acc[i][j] is the 16x16 fragment (i, j) of this wave's (BM/2) x (BN/2) sub-tile
@@ -74,7 +84,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
                             v[r] = h * gelu_for<T>(gt);
                         }
                         const int no = (nbase) / 2 + (j / 2) * 16 + 4 * g;
-                        store4(outT + (long)m * p.ldo + no, v);
+                        if (p.flags & IG_OUT_PAIR) store_pair_row4(reinterpret_cast<bf16*>(p.out) + (long)m * p.ldo + no, p.ldo / 2, v);
+                        else store4(outT + (long)m * p.ldo + no, v);
                     }
                 }
             }
@@ -102,7 +113,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] += rr[r];
                         }
-                        if (out_f32)
+                        if (p.flags & IG_OUT_PAIR)
+                            store_pair_row4(reinterpret_cast<bf16*>(p.out) + (long)m * p.ldo + n, p.ldo / 2, v);
+                        else if (out_f32)
                             store4(outF + (long)m * p.ldo + n, v);
                         else
                             store4(outT + (long)m * p.ldo + n, v);
@@ -777,7 +790,9 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmPar
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += rr[r];
         }
-        if (p.flags & IG_OUT_F32)
+        if (p.flags & IG_OUT_PAIR)
+            store_pair_row4(reinterpret_cast<bf16*>(p.out) + (long)m * p.ldo + n, p.ldo / 2, v);
+        else if (p.flags & IG_OUT_F32)
             store4(outF + (long)m * p.ldo + n, v);
         else
             store4(outT + (long)m * p.ldo + n, v);

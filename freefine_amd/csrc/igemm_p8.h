@@ -89,8 +89,9 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     constexpr int NB1 = (FN + 1) / 2;       // B pieces requested in phase 1 (the rest in phase 2)
     // store instructions of one half-tile epilogue (every one is issued: no lane predicate around them); bf16 row-major output goes
     // out as pairs of fragments (store_rows)
-    constexpr int NST = (SPLIT || TRANS || X3) ? (GEGLU ? FH * FN / 2 : FH * FN) : (GEGLU ? FH * FN / 2 : FH * ((FN + 1) / 2));
-    constexpr int OSZ = X3 ? 4 : 2;         // bytes per output / residual element
+    // X3 GEGLU writes the bf16 PAIR form (hi and lo planes: two 8-byte stores per fragment pair) -- its only consumer is the next GEMM
+    constexpr int NST = (SPLIT || TRANS || X3) ? FH * FN : (GEGLU ? FH * FN / 2 : FH * ((FN + 1) / 2));
+    constexpr int OSZ = (X3 && !GEGLU) ? 4 : 2;         // bytes per output / residual element
     constexpr int OOB = (int)0x80000000;
     static_assert((BM == 256 || BM == 192) && (BN == 256 || BN == 320), "tiles built for this kernel");
     static_assert(!GEGLU || FN % 2 == 0, "GEGLU pairs hidden / gate column blocks inside a wave");
@@ -426,13 +427,22 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
 #pragma unroll
             for (int i = i0; i < i0 + FH; ++i) {
                 const int vo = m0 + i * 16 + pr < p.M ? voff : OOB;
-                if constexpr (GEGLU) {
+                if constexpr (GEGLU) {                // pair form: out is bf16 [M][ldo], hi at column n, lo at ldo/2 + n
+                    const int vo2 = m0 + i * 16 + pr < p.M ? (pr * p.ldo + 4 * pg) * 2 : OOB;
 #pragma unroll
                     for (int j = 0; j + 1 < FN; j += 2) {
-                        u32x4 w;
+                        float v[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) w[r] = perm(__float_as_uint(acc[i][j][r] * gelu_erf_fast(acc[i][j + 1][r])));
-                        __builtin_amdgcn_raw_buffer_store_b128(w, rsrcO, vo, ((m0 + i * 16) * p.ldo + n0 / 2 + (j / 2) * 16) * 4, 0);
+                        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * gelu_erf_fast(acc[i][j + 1][r]);
+                        u32x2 hi, lo;
+                        hi[0] = pack_bf16x2(v[0], v[1]);
+                        hi[1] = pack_bf16x2(v[2], v[3]);
+                        lo[0] = pack_bf16x2(v[0] - __uint_as_float(hi[0] << 16), v[1] - __uint_as_float(hi[0] & 0xffff0000u));
+                        lo[1] = pack_bf16x2(v[2] - __uint_as_float(hi[1] << 16), v[3] - __uint_as_float(hi[1] & 0xffff0000u));
+                        hi[0] = perm(hi[0]); hi[1] = perm(hi[1]); lo[0] = perm(lo[0]); lo[1] = perm(lo[1]);
+                        const int so = ((m0 + i * 16) * p.ldo + n0 / 2 + (j / 2) * 16) * 2;
+                        __builtin_amdgcn_raw_buffer_store_b64(hi, rsrcO, vo2, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(lo, rsrcO, vo2, so + p.ldo, 0);      // + ldo/2 elements = ldo bytes
                     }
                 } else {
 #pragma unroll

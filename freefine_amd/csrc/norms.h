@@ -8,6 +8,18 @@
 #pragma once
 #include "common.h"
 
+// PAIR output (split-bf16 mode, T = float): the normalised row is written as the bf16 pair [hi(C) | lo(C)] an FFN_BF16X3 GEMM reads as its
+// A operand (hi = bf16(v), lo = bf16(v - hi)) instead of fp32 -- same bytes, and the separate ffn_split_pair pass disappears.
+__device__ __forceinline__ void store_pair4(bf16* yp, long row, int C, int c, const float* f) {
+    u32x2 hi, lo;
+    hi[0] = pack_bf16x2(f[0], f[1]);
+    hi[1] = pack_bf16x2(f[2], f[3]);
+    lo[0] = pack_bf16x2(f[0] - __uint_as_float(hi[0] << 16), f[1] - __uint_as_float(hi[0] & 0xffff0000u));
+    lo[1] = pack_bf16x2(f[2] - __uint_as_float(hi[1] << 16), f[3] - __uint_as_float(hi[1] & 0xffff0000u));
+    *reinterpret_cast<u32x2*>(yp + row * 2 * C + c) = hi;
+    *reinterpret_cast<u32x2*>(yp + row * 2 * C + C + c) = lo;
+}
+
 // ---- (1) partial sums: grid (nchunk, B), 256 threads ------------------------------------------------------
 // partial[b][chunk][c][2] = (sum, sumsq) over the chunk's pixels
 template <typename T>
@@ -110,7 +122,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 }
 
 // ---- (3) apply: y = act(x*scale[b][c] + shift[b][c]) ------------------------------------------------------
-template <typename T, bool SILU>
+template <typename T, bool SILU, bool PAIR = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        long nchunks_total, int HW, int C) {
@@ -131,14 +143,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
             if (SILU) t = silu_exact(t);
             f[e] = t;
         }
-        *reinterpret_cast<u32x4*>(y + i * EPC) = DT<T>::pack(f);
+        if constexpr (PAIR) store_pair4(reinterpret_cast<bf16*>(y), pix, C, cc * EPC, f);
+        else *reinterpret_cast<u32x4*>(y + i * EPC) = DT<T>::pack(f);
     }
 }
 
 // ---- fused GroupNorm for slices that one workgroup can own: grid (G, B), 1024 threads ----------------------------------
 // pass 1: sum / sumsq over the (batch, group) slice [HW][cg] (element pairs, 4 or 8 bytes per load; the slice is L2 resident),
 // block reduction (fp32 per thread, fp64 across threads), pass 2: y = act((x - mean) * rstd * gamma + beta).
-template <typename T, bool SILU>
+template <typename T, bool SILU, bool PAIR = false>
 __global__ __launch_bounds__(1024) void gn_fused_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int HW, int C, int G, float eps) {
     __shared__ double red[2][16];
@@ -190,13 +203,21 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const T* __restrict__ x,
             a = silu_exact(a);
             d = silu_exact(d);
         }
-        DT<T>::st(y + off, a);
-        DT<T>::st(y + off + 1, d);
+        if constexpr (PAIR) {
+            bf16* yp = reinterpret_cast<bf16*>(y);
+            const long prow = ((long)b * HW + px) * 2 * C;
+            const uint32_t hi = pack_bf16x2(a, d);
+            *reinterpret_cast<uint32_t*>(yp + prow + c) = hi;
+            *reinterpret_cast<uint32_t*>(yp + prow + C + c) = pack_bf16x2(a - __uint_as_float(hi << 16), d - __uint_as_float(hi & 0xffff0000u));
+        } else {
+            DT<T>::st(y + off, a);
+            DT<T>::st(y + off + 1, d);
+        }
     }
 }
 
 // ---- LayerNorm over C per row; one wave per row, two-pass in registers --------------------------------------
-template <typename T, int MAXCH>  // MAXCH = max 16-byte chunks per lane
+template <typename T, int MAXCH, bool PAIR = false>  // MAXCH = max 16-byte chunks per lane
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int M, int C, float eps) {
@@ -243,7 +264,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
                 const int c = cc * EPC + e;
                 o[e] = (f[i][e] - mean) * rstd * gamma[c] + beta[c];
             }
-            *reinterpret_cast<u32x4*>(y + (long)row * C + cc * EPC) = DT<T>::pack(o);
+            if constexpr (PAIR) store_pair4(reinterpret_cast<bf16*>(y), row, C, cc * EPC, o);
+            else *reinterpret_cast<u32x4*>(y + (long)row * C + cc * EPC) = DT<T>::pack(o);
         }
     }
 }

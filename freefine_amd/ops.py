@@ -142,6 +142,16 @@ def pack_geglu(w, b, dtype, x3=False):
     return wp, bp
 
 
+def _mark_pair(t, C):
+    t._ffn_pair = C            # bf16 [..., 2C] = [hi(C) | lo(C)]: the A operand of an FFN_BF16X3 GEMM
+    return t
+
+
+def pair_width(x):
+    """C if x is a split-bf16 pair tensor [..., 2C], else None"""
+    return getattr(x, "_ffn_pair", None)
+
+
 def split_pair(x, K=None):
     """fp32 [..., ld] (first K columns) -> bf16 PAIR rows [..., 2K] = [hi | lo] (ffn_split_pair): the A operand of an FFN_BF16X3 GEMM"""
     lib = L.load()
@@ -152,7 +162,7 @@ def split_pair(x, K=None):
     out = torch.empty(*x.shape[:-1], 2 * K, dtype=torch.bfloat16, device=x.device)
     L.check(_timed("split_pair_kernel", 0.0, 8.0 * rows * K, lambda: lib.ffn_split_pair(_stream(), x.data_ptr(), out.data_ptr(), rows, K, ld)),
             "ffn_split_pair")
-    return out
+    return _mark_pair(out, K)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -171,7 +181,7 @@ def _workspace(device):
     return ws
 
 def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, rows_per_batch=None, silu=False,
-           geglu=False, out_f32=False, transposed_ld=None, alpha=1.0, splitk=0):
+           geglu=False, out_f32=False, transposed_ld=None, alpha=1.0, splitk=0, out_pair=False):
     """out = x @ w[:, :K]^T (+bias ...).  x: [..., K] contiguous rows (M = prod of leading dims)."""
     lib = L.load()
     K = K if K is not None else x.shape[-1]
@@ -179,13 +189,19 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
     N = w.shape[0]
     d = L.IgemmDesc()
     x3 = is_x3(w)
-    xa = split_pair(x, K) if x3 else x              # split-bf16: fp32 activations -> [hi | lo] bf16 rows; results / residual stay fp32
+    if x3 and pair_width(x) is not None:            # the producer (norm / GEGLU / attention) already wrote the [hi | lo] pair rows
+        K = pair_width(x)
+        M = x.numel() // x.shape[-1]
+        xa = x
+    else:
+        xa = split_pair(x, K) if x3 else x          # split-bf16: fp32 activations -> [hi | lo] bf16 rows; results / residual stay fp32
     dcode = L.FFN_BF16X3 if x3 else _dt(x)
     d.A, d.W = xa.data_ptr(), w.data_ptr()
     d.bias, d.rowbias, d.residual = _p(bias), _p(rowbias), _p(residual)
     d.M, d.N, d.K, d.Kpad = M, N, K, w.stride(0)    # Kpad = row stride of W (an activation view can serve as W)
     d.lda = xa.stride(-2) if xa.ndim > 1 else xa.shape[-1]
     d.a_lo = K if x3 else 0
+    odt = torch.float32 if x3 else x.dtype          # element type of out / residual
     d.rows_per_batch = rows_per_batch or M
     d.ldrb = rowbias.stride(0) if rowbias is not None else 0
     flags = 0
@@ -204,11 +220,16 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
             # columns past the rows of a batch are padding the attention kernels may multiply by P = 0: they must be finite, so a
             # padded buffer is zero-filled; without padding (every UNet level: S % 8 == 0) the GEMM writes every element
             alloc = torch.zeros if transposed_ld > d.rows_per_batch else torch.empty
-            out = alloc(nb, N, transposed_ld, dtype=x.dtype, device=x.device)
+            out = alloc(nb, N, transposed_ld, dtype=odt, device=x.device)
         d.ldo = transposed_ld
+    elif out_pair:                                  # split-bf16 only: the result in the pair form the next GEMM reads
+        assert x3 and residual is None and out is None
+        flags |= L.IG_OUT_PAIR
+        out = _mark_pair(torch.empty(*x.shape[:-1], 2 * n_out, dtype=torch.bfloat16, device=x.device), n_out)
+        d.ldo = 2 * n_out
     else:
         if out is None:
-            out = torch.empty(*x.shape[:-1], n_out, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+            out = torch.empty(*x.shape[:-1], n_out, dtype=torch.float32 if out_f32 else odt, device=x.device)
         d.ldo = out.stride(-2) if out.ndim > 1 else n_out          # a column view of a wider buffer (cat_dst) keeps the buffer's row stride
     d.ldr = residual.shape[-1] if residual is not None else 0
     d.out = out.data_ptr()
@@ -234,8 +255,13 @@ def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, ou
     N = w.shape[0]
     d = L.IgemmDesc()
     x3 = is_x3(w)
-    xa = split_pair(x, Cin) if x3 else x            # split-bf16: every pixel becomes [hi(Cin) | lo(Cin)]
+    if x3 and pair_width(x) is not None:
+        assert pair_width(x) == Cin
+        xa = x
+    else:
+        xa = split_pair(x, Cin) if x3 else x        # split-bf16: every pixel becomes [hi(Cin) | lo(Cin)]
     dcode = L.FFN_BF16X3 if x3 else _dt(x)
+    odt = torch.float32 if x3 else x.dtype
     d.A, d.W = xa.data_ptr(), w.data_ptr()
     d.bias, d.rowbias, d.residual = _p(bias), _p(rowbias), _p(residual)
     d.M, d.N, d.K, d.Kpad = B * Hout * Wout, N, 9 * Cin, w.shape[1]
@@ -244,7 +270,7 @@ def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, ou
     d.rows_per_batch = Hout * Wout
     d.ldrb = (rowbias_ld or rowbias.stride(0)) if rowbias is not None else 0
     if out is None:
-        out = torch.empty(B, Hout * Wout, N, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+        out = torch.empty(B, Hout * Wout, N, dtype=torch.float32 if out_f32 else odt, device=x.device)
     d.out, d.ldo = out.data_ptr(), out.stride(-2)                   # (a column view of a wider buffer keeps the buffer's row stride)
     d.ldr = residual.shape[-1] if residual is not None else 0
     d.Hin, d.Win, d.Cin, d.Hout, d.Wout = Hin, Win, Cin, Hout, Wout
@@ -289,7 +315,7 @@ class AttnEntrySpec:
                              self.flags, logical_row if self.hr_row is None else self.hr_row)
 
 
-def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=None, Bo=None, C=None, x3=False):
+def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=None, Bo=None, C=None, x3=False, out_pair=False):
     """q: [Bq,S,C]; k: [Bk,Sk,C]; vt: [Bk,C,ldvt] (V transposed).  passes: list (per pass) of lists (per output
     row) of AttnEntrySpec or None (= skipped).  passes=None -> plain attention, row b uses its own K/V.
     More than FFN_ATT_MAXB output rows are issued as several launches over row ranges (entries name absolute Q/KV rows)."""
@@ -301,6 +327,9 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
     if passes is None:
         passes = [[AttnEntrySpec(b, b) for b in range(Bq)]]
     Bo = Bo if Bo is not None else len(passes[0])
+    out_pair = bool(out_pair and x3 and q.dtype == torch.float32 and Dh <= 64 and out is None and Cq % 8 == 0)
+    if out_pair:                                     # the result as pair rows for the to_out projection's split-bf16 GEMM
+        out = _mark_pair(torch.empty(Bo, S, 2 * Cq, dtype=torch.bfloat16, device=q.device), Cq)
     if out is None:
         out = torch.empty(Bo, S, Cq, dtype=q.dtype, device=q.device)
     for rows in passes:
@@ -311,9 +340,10 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
         nb = min(L.ATT_MAXB, Bo - b0)
         d = L.AttnDesc()
         d.q, d.k, d.vt, d.w_dev = q.data_ptr(), k.data_ptr(), vt.data_ptr(), _p(w_dev)
-        d.out = out.data_ptr() + b0 * S * Cq * esz
+        d.out = out.data_ptr() + b0 * S * Cq * esz       # (pair rows: 2 Cq bf16 = Cq fp32 worth of bytes)
         d.Bo, d.S, d.Sk, d.heads, d.D = nb, S, Sk, heads, Dh
-        d.ldq, d.ldk, d.ldvt, d.ldo = q.stride(1), k.stride(1), vt.stride(1), Cq
+        d.ldq, d.ldk, d.ldvt, d.ldo = q.stride(1), k.stride(1), vt.stride(1), (2 * Cq if out_pair else Cq)
+        d.out_pair = 1 if out_pair else 0
         d.scale, d.npass = scale, len(passes)
         for p, rows in enumerate(passes):
             for b in range(nb):
@@ -349,18 +379,23 @@ def gn_workspace(B, HW, C, device):
             torch.empty(B, C, dtype=torch.float32, device=device), torch.empty(B, C, dtype=torch.float32, device=device))
 
 
-def groupnorm(x, gamma, beta, G, eps, silu=False, out=None, ws=None):
-    """x: [B, HW, C].  One fused launch for slices <= 131072 elements per (batch, group), else stats + apply."""
+def groupnorm(x, gamma, beta, G, eps, silu=False, out=None, ws=None, pair=False):
+    """x: [B, HW, C].  One fused launch for slices <= 131072 elements per (batch, group), else stats + apply.
+    pair (fp32 x): the result as the bf16 pair rows [B, HW, 2C] an FFN_BF16X3 GEMM reads."""
     lib = L.load()
     B, HW, Cc = x.shape
+    if pair:
+        assert x.dtype == torch.float32 and out is None
+        out = _mark_pair(torch.empty(B, HW, 2 * Cc, dtype=torch.bfloat16, device=x.device), Cc)
     if out is None:
         out = torch.empty_like(x)
     if lib.ffn_gn_fused(B, HW, Cc, G):
         partial = scale = shift = None
     else:
         partial, scale, shift = ws if ws is not None else gn_workspace(B, HW, Cc, x.device)
+    fl = (L.NORM_SILU if silu else 0) | (L.NORM_OUT_PAIR if pair else 0)
     call = lambda: lib.ffn_groupnorm(_stream(), _dt(x), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B, HW, Cc, G, eps,
-                                     1 if silu else 0, _p(partial), _p(scale), _p(shift))
+                                     fl, _p(partial), _p(scale), _p(shift))
     if _PROF is None:
         L.check(call(), "ffn_groupnorm")
     else:       # algorithmic bytes: one read + one write (the three-launch form reads x twice: that shows as a lower GB/s)
@@ -369,13 +404,18 @@ def groupnorm(x, gamma, beta, G, eps, silu=False, out=None, ws=None):
     return out
 
 
-def layernorm(x, gamma, beta, eps=1e-5, out=None):
+def layernorm(x, gamma, beta, eps=1e-5, out=None, pair=False):
     lib = L.load()
     Cc = x.shape[-1]
     M = x.numel() // Cc
-    if out is None:
-        out = torch.empty_like(x)
-    call = lambda: lib.ffn_layernorm(_stream(), _dt(x), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, Cc, eps)
+    if pair:
+        assert x.dtype == torch.float32 and out is None
+        out = _mark_pair(torch.empty(*x.shape[:-1], 2 * Cc, dtype=torch.bfloat16, device=x.device), Cc)
+        call = lambda: lib.ffn_layernorm_pair(_stream(), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, Cc, eps)
+    else:
+        if out is None:
+            out = torch.empty_like(x)
+        call = lambda: lib.ffn_layernorm(_stream(), _dt(x), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, Cc, eps)
     if _PROF is None:
         L.check(call(), "ffn_layernorm")
     else:

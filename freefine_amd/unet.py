@@ -474,7 +474,8 @@ class HipUNet:
 
     def _gn(self, x, gb, eps, silu):
         B, HW, C = x.shape
-        return ops.groupnorm(x, gb[0], gb[1], self.cfg.norm_num_groups, eps, silu=silu)
+        # split-bf16 mode: every GroupNorm / LayerNorm feeds a GEMM -> written directly in the [hi | lo] pair form that GEMM reads
+        return ops.groupnorm(x, gb[0], gb[1], self.cfg.norm_num_groups, eps, silu=silu, pair=self.x3)
 
     def _resblock(self, r, x, B, H, W, temb_all, out=None):
         cin = x.shape[-1]
@@ -490,15 +491,16 @@ class HipUNet:
         D = t.C // t.heads
         scale = D ** -0.5
         if self.controller is None:
-            return ops.attention(q, k, vt, t.heads, scale, None, Sk=Sk, C=t.C, x3=self.x3)
+            return ops.attention(q, k, vt, t.heads, scale, None, Sk=Sk, C=t.C, x3=self.x3, out_pair=self.x3)
         plan = self._plan(is_cross, place, B, S, t.heads)
         if plan["kind"] == "shared_kv":
             rr = plan["ref_rows"]
             kc = k[..., :t.C] if k.shape[-1] != t.C else k
             k2 = torch.cat([kc, kc[rr]], dim=1).contiguous()                 # device-memory plumbing (non-default SSA/SDSA path)
             vt2 = torch.cat([vt[..., :Sk], vt[rr][..., :Sk]], dim=2).contiguous()
-            return ops.attention(q, k2, vt2, t.heads, scale, plan["passes"], Sk=2 * Sk, C=t.C, x3=self.x3)
-        return ops.attention(q, k, vt, t.heads, scale, plan["passes"], Sk=Sk, C=t.C, w_dev=self.cg_dev if plan["needs_cg"] else None, x3=self.x3)
+            return ops.attention(q, k2, vt2, t.heads, scale, plan["passes"], Sk=2 * Sk, C=t.C, x3=self.x3, out_pair=self.x3)
+        return ops.attention(q, k, vt, t.heads, scale, plan["passes"], Sk=Sk, C=t.C, w_dev=self.cg_dev if plan["needs_cg"] else None, x3=self.x3,
+                             out_pair=self.x3)
 
     def _transformer_block(self, t, x, B, H, W, place, kv_text, out=None):
         S, C = H * W, t.C
@@ -506,20 +508,20 @@ class HipUNet:
         h = self._gn(x, t.norm, 1e-6, False)
         h = ops.linear(h, t.proj_in[0], t.proj_in[1], K=C)
         # --- self attention
-        y = ops.layernorm(h, *t.ln[0])
+        y = ops.layernorm(h, *t.ln[0], pair=self.x3)
         qk = ops.linear(y, t.w_qk1, None, K=C)                                  # [B,S,2C]: q | k
         vt = ops.linear(y, t.w_v1, None, K=C, rows_per_batch=S, transposed_ld=(S + 7) // 8 * 8)   # V^T [B,C,S]
         a = self._attention(t, False, place, qk, qk[..., C:], vt, 2 * C, B, S, S)
         h = ops.linear(a, t.o1[0], t.o1[1], K=C, residual=h)
         # --- cross attention
-        y = ops.layernorm(h, *t.ln[1])
+        y = ops.layernorm(h, *t.ln[1], pair=self.x3)
         q = ops.linear(y, t.w_q2, None, K=C)
         k2, vt2 = kv_text
         a = self._attention(t, True, place, q, k2, vt2, C, B, S, k2.shape[1])
         h = ops.linear(a, t.o2[0], t.o2[1], K=C, residual=h)
         # --- feed forward (GEGLU fused in the first GEMM's epilogue)
-        y = ops.layernorm(h, *t.ln[2])
-        y = ops.linear(y, t.ff1[0], t.ff1[1], K=C, geglu=True)
+        y = ops.layernorm(h, *t.ln[2], pair=self.x3)
+        y = ops.linear(y, t.ff1[0], t.ff1[1], K=C, geglu=True, out_pair=self.x3)
         h = ops.linear(y, t.ff2[0], t.ff2[1], K=4 * C, residual=h)
         return ops.linear(h, t.proj_out[0], t.proj_out[1], K=C, residual=res0, out=out)
 

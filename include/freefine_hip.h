@@ -45,7 +45,9 @@ enum {
     FFN_IG_OUT_SILU = 1 << 0,
     FFN_IG_OUT_F32 = 1 << 1,
     FFN_IG_GEGLU = 1 << 2,         /* N = 2*Nout; 16-column blocks alternate hidden/gate; out = hidden * gelu(gate) */
-    FFN_IG_OUT_TRANSPOSED = 1 << 3 /* out[b][n][s], row stride ldo, m = b*rows_per_batch + s (V^T for ffn_attn) */
+    FFN_IG_OUT_TRANSPOSED = 1 << 3, /* out[b][n][s], row stride ldo, m = b*rows_per_batch + s (V^T for ffn_attn) */
+    FFN_IG_OUT_PAIR = 1 << 4        /* FFN_BF16X3 only: out is the bf16 PAIR form [M][ldo], hi at column n, lo at column ldo/2 + n -- the A operand
+                                       of the next FFN_BF16X3 GEMM (the GEGLU projection feeding ff.net.2); no residual */
 };
 typedef struct ffn_igemm_desc {
     const void* A;        /* dense: [M][lda];  conv: NHWC input [B][Hin][Win][Cin] */
@@ -139,6 +141,9 @@ typedef struct ffn_attn_desc {
     int ldq, ldk, ldvt, ldo;
     float scale;
     int npass;
+    int out_pair;       /* FFN_BF16X3 with D <= 64 only: out is the bf16 PAIR form [Bo][S][ldo] (hi at column c, lo at ldo/2 + c), the A operand of
+                           the to_out projection's FFN_BF16X3 GEMM; 0 = fp32 rows */
+    int reserved;
     ffn_attn_entry e[FFN_ATT_MAXP * FFN_ATT_MAXB]; /* entry (p,b) at p*FFN_ATT_MAXB + b */
 } ffn_attn_desc;
 int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d);
@@ -155,6 +160,9 @@ int ffn_attn_variant(int dtype, int D, int* dp, int* qf);
 int ffn_attn_kernel_name(int dtype, const ffn_attn_desc* d, char* buf, int len);
 
 /* ---- normalisation ------------------------------------------------------------------------------------------- */
+/* `silu` of ffn_groupnorm / ffn_gn_apply is a flag word: FFN_NORM_SILU applies SiLU; FFN_NORM_OUT_PAIR (fp32 input only) writes y as the
+ * bf16 PAIR rows [B*HW][2C] = [hi | lo] an FFN_BF16X3 GEMM reads (no separate ffn_split_pair pass).  ffn_layernorm_pair: the same for LayerNorm. */
+enum { FFN_NORM_SILU = 1, FFN_NORM_OUT_PAIR = 2 };
 /* GroupNorm statistics -> per-(batch,channel) scale/shift (fp32).  partial_ws: >= B*nchunk*2*C floats where
  * nchunk = ffn_gn_nchunk(HW).  Replaces torch GroupNorm inside diffusers blocks (attention.py:105-214). */
 int ffn_gn_nchunk(int HW);
@@ -170,6 +178,7 @@ int ffn_groupnorm(void* stream, int dtype, const void* x, void* y, const float* 
                   float eps, int silu, float* partial_ws, float* scale, float* shift);
 int ffn_layernorm(void* stream, int dtype, const void* x, void* y, const float* gamma, const float* beta, int M, int C,
                   float eps);
+int ffn_layernorm_pair(void* stream, const float* x, void* y, const float* gamma, const float* beta, int M, int C, float eps);
 int ffn_softmax_rows(void* stream, int dtype, const void* x, void* y, long M, int N, float scale);
 
 /* ---- scheduler / guidance elementwise (fp32, NCHW like the reference) ------------------------------------------ */
