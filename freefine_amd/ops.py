@@ -308,11 +308,12 @@ class AttnEntrySpec:
             raise ValueError(f"attention term (q row {self.q_row}, kv row {self.kv_row}) reaches outside the rows of this phase {sorted(ren)}")
         return AttnEntrySpec(ren[self.q_row], ren[self.kv_row], self.w_const, self.w_slope, self.wq, self.kmask, self.qsel, self.flags, self.hr_row)
 
-    def shifted(self, base, logical_row):
-        """the same term inside an image-batched launch: this image's physical rows start at `base`; the tiled-head rule
-        (attention.py:859 vs 761) keeps using the row index the image would have had in its own batch"""
-        return AttnEntrySpec(self.q_row + base, self.kv_row + base, self.w_const, self.w_slope, self.wq, self.kmask, self.qsel,
-                             self.flags, logical_row if self.hr_row is None else self.hr_row)
+    def shifted(self, base, logical_row, kv_base=None):
+        """the same term inside an image-batched launch: this image's physical rows start at `base` (its K / V rows at `kv_base`
+        where they differ: cross attention of the composition hook, whose text batch has more rows than the latent batch); the
+        tiled-head rule (attention.py:859 vs 761) keeps using the row index the image would have had in its own batch"""
+        return AttnEntrySpec(self.q_row + base, self.kv_row + (base if kv_base is None else kv_base), self.w_const, self.w_slope, self.wq,
+                             self.kmask, self.qsel, self.flags, logical_row if self.hr_row is None else self.hr_row)
 
 
 def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=None, Bo=None, C=None, x3=False, out_pair=False):

@@ -261,6 +261,13 @@ class FreeFinePipeline:
     def preprocess_image(self, image, device=None):
         return (torch.from_numpy(image).float() / 127.5 - 1).permute(2, 0, 1).unsqueeze(0).to(self.device)
 
+    @staticmethod
+    def _work_size(img):
+        """[W, H] bound the other images of an edit are thumbnailed to.  The reference hard-codes 512 x 512 (model.py:1347, :1369);
+        here the bound follows the coarse input when that is larger (768 x 768 edits, BASELINE.json configs[4]) and is the
+        reference's 512 otherwise, so every call the reference can make behaves as it does there."""
+        return [max(512, img.shape[1]), max(512, img.shape[0])]
+
     def resize_img(self, img, size=None):
         """model.py:1332-1340: PIL thumbnail (never upscales); a no-op for the <=512 inputs of the drivers."""
         if max(img.shape[:2]) <= max(size):
@@ -646,7 +653,7 @@ class FreeFinePipeline:
 
     @torch.no_grad()
     def DDIM_inversion_func(self, img, mask, prompt, num_step, start_step=0, ref_img=None, verbose=False):
-        imgs = [img] if ref_img is None else [img, self.resize_img(ref_img, size=[512, 512])]
+        imgs = [img] if ref_img is None else [img, self.resize_img(ref_img, size=self._work_size(img))]
         source = torch.from_numpy(np.stack(imgs))                       # uint8 [N,H,W,3]; /127.5-1 happens in the VAE's first kernel
         mask = self.prepare_controller_ref_mask(mask, False)
         latents, latents_list = self.invert(source, prompt, guidance_scale=1.0, num_inference_steps=num_step,
@@ -657,7 +664,7 @@ class FreeFinePipeline:
 
     @torch.no_grad()
     def DDIM_inversion_func_compose(self, img, compose_imgs, prompt, num_step, start_step=0, verbose=False):
-        imgs = [img] + [self.resize_img(r, size=[512, 512]) for r in compose_imgs]
+        imgs = [img] + [self.resize_img(r, size=self._work_size(img)) for r in compose_imgs]
         source = torch.from_numpy(np.stack(imgs))
         latents, latents_list = self.invert(source, prompt, guidance_scale=1.0, num_inference_steps=num_step,
                                             num_actual_inference_steps=num_step - start_step, return_intermediates=True, verbose=verbose)
@@ -805,7 +812,7 @@ class FreeFinePipeline:
         gens = [torch.Generator().manual_seed(s) for s in seeds]
         red = self.mask_reduce_dim
         # ---- inversion of [coarse_i, ori_i] for every image: one 2K-row batch (model.py:1341-1388 + 816-925)
-        source = torch.from_numpy(np.concatenate([np.stack([c["coarse_input"], self.resize_img(c["ori_img"], size=[512, 512])])
+        source = torch.from_numpy(np.concatenate([np.stack([c["coarse_input"], self.resize_img(c["ori_img"], size=self._work_size(c["coarse_input"]))])
                                                   for c in cases]))
         for c in ctrls:
             c.reset()
@@ -977,6 +984,95 @@ class FreeFinePipeline:
             for c in ctrls:
                 c.reset()
             images = self.latent2image(latents[0::2].contiguous(), return_type="pt")      # only the generated rows are returned (model.py:1118)
+            self.last_intermediates = inter
+            return [(images[k].permute(1, 2, 0).detach().cpu().numpy() * 255).astype(np.uint8) for k in range(K)]
+        finally:
+            self.controller = single
+            self.unet.controller = single
+
+    @torch.no_grad()
+    def FreeFine_cross_image_composition_batch(self, cases, guidance_scale, eta, end_step=10, num_step=50, start_step=25, share_attn=True,
+                                               method_type="tca", local_text_edit=True, local_perturbation=True, verbose=True, seeds=42,
+                                               return_intermediates=False, end_scale=0.5, dil_completion=False, dil_factor=15,
+                                               appearance_transfer=False):
+        """K independent FreeFine_cross_image_composition calls (model.py:1051-1086 each: appearance transfer / cross-image composition,
+        BASELINE.json configs[3]) as ONE image-major batch: the inversion runs K (1 + R) rows, the guided loop K (R + 2) latent rows
+        [edit_u, ref_1 .. ref_R, edit_c] against K (1 + R + P) text rows.  All cases share R (reference images) and P - 1 (prompts).
+        Needs the composition hook (register_attention_control_compose).  cases: dicts with img_lists, ori_mask_lists, tgt_mask_lists,
+        coarse_input, guidance_text_list (+ optional draw_mask).  Returns a list of images; image i equals the single call with
+        seed seeds[i]."""
+        assert method_type in self._METHODS and guidance_scale > 1.0
+        assert self.unet.hook == "compose", "register_attention_control_compose(model, controller) first"
+        K = len(cases)
+        R, P = len(cases[0]["img_lists"]), len(cases[0]["guidance_text_list"]) + 1
+        assert all(len(c["img_lists"]) == R and len(c["guidance_text_list"]) + 1 == P for c in cases), "batched compositions share R and the prompt count"
+        seeds = [seeds] * K if isinstance(seeds, int) else list(seeds)
+        single = self.controller
+        ctrls = self._controllers_for_batch(K)
+        self.unet.controller = ctrls if K > 1 else single
+        try:
+            seed_everything(seeds[0])
+            gens = [torch.Generator().manual_seed(sd) for sd in seeds]
+            red = self.mask_reduce_dim
+            source = torch.from_numpy(np.concatenate([np.stack([c["coarse_input"]] + [self.resize_img(r, size=self._work_size(c["coarse_input"]))
+                                                                                      for r in c["img_lists"]]) for c in cases]))
+            for c in ctrls:
+                c.reset()
+            _, inverted = self.invert(source, "", guidance_scale=1.0, num_inference_steps=num_step,
+                                      num_actual_inference_steps=num_step - start_step, return_intermediates=True)
+            for c in ctrls:
+                c.reset()
+            init, refer = inverted[-1], inverted[::-1]                     # [K (1 + R), 4, h, w]
+            shape1 = tuple(init.shape[1:])
+            cfg_f, var_masks, texts = [], [], []
+            for case, c in zip(cases, ctrls):
+                full_h, full_w = case["coarse_input"].shape[:2]
+                tgt_t, ori_t, lp, cfg_m = self.prepare_composition_masks([red(m) for m in case["ori_mask_lists"]], [red(m) for m in case["tgt_mask_lists"]],
+                                                                         full_h, full_w, init, dil_completion=dil_completion, dil_factor=dil_factor,
+                                                                         draw_mask=case.get("draw_mask"), appearance_transfer=appearance_transfer)
+                c.src_masks, c.tgt_masks = ori_t, tgt_t
+                c.reset()
+                self.controller = c
+                self._configure_method(method_type, share_attn)
+                c.local_edit = local_text_edit
+                c.prompt_length = P
+                cfg_f.append(self._mask_f(cfg_m) if local_text_edit else None)
+                var_masks.append(lp if local_perturbation else torch.ones_like(lp))
+                texts.append(torch.cat([self._encode_text([""] * (1 + R)), self._encode_text(list(case["guidance_text_list"]) + [""])], dim=0))
+            self.controller = ctrls[0]
+            text_all = torch.cat(texts, dim=0).contiguous()
+            self.scheduler.set_timesteps(num_step)
+            n_act = num_step - start_step
+            noises = []
+            for g in gens:
+                self._gen = g
+                noises.append(self._predraw_noise(n_act, (1,) + shape1, eta))
+            latents = init.clone().view(K, 1 + R, *shape1)                 # rows (edit_i, ref_i1 .. ref_iR)
+            # latent rows of the UNet batch: per image [0 .. R, 0]
+            row_idx = torch.tensor([i * (1 + R) + r for i in range(K) for r in list(range(1 + R)) + [0]], device=self.device)
+            inter = [[init.view(K, 1 + R, *shape1)[k]] for k in range(K)] if return_intermediates else None
+            for i, t in enumerate(self.scheduler.timesteps):
+                if i < start_step:
+                    continue
+                latents[:, 1:] = refer[i - start_step + 1].view(K, 1 + R, *shape1)[:, 1:]
+                for c in ctrls:
+                    if method_type == "tca":
+                        c.context_guidance = self.linear_param(i, start_step, end_step, num_step, end_scale=end_scale)
+                    elif method_type == "mmsa_es" and i >= end_step:
+                        c.use_tca = False
+                eps = self.unet(latents.view(K * (1 + R), *shape1).index_select(0, row_idx), t, encoder_hidden_states=text_all)
+                eps = eps.view(K, R + 2, *shape1)
+                new = latents.clone()
+                for k in range(K):
+                    e = ops.cfg_masked(eps[k, :1].contiguous(), eps[k, -1:].contiguous(), cfg_f[k], guidance_scale)
+                    new[k, :1] = self.ctrl_step(e, t, latents[k, :1].contiguous(), var_masks[k], eta=eta,
+                                                noise=None if noises[k] is None else noises[k][i - start_step])[0]
+                    if inter is not None:
+                        inter[k].append(new[k, 0])
+                latents = new
+            for c in ctrls:
+                c.reset()
+            images = self.latent2image(latents[:, 0].contiguous(), return_type="pt")
             self.last_intermediates = inter
             return [(images[k].permute(1, 2, 0).detach().cpu().numpy() * 255).astype(np.uint8) for k in range(K)]
         finally:

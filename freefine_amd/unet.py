@@ -43,6 +43,7 @@ class HipUNet:
         self._row_idx = {}
         self._reuse, self._reuse_idx, self._enc_a, self.last_boundary = None, {}, {}, None
         self._in_phase_a = False
+        self._enc_rows = 0
         self.reuse_replays = 0             # forwards whose reference rows re-entered from a recorded state (tests / bench report it)
         self._pack(state)
 
@@ -235,6 +236,7 @@ class HipUNet:
         sample = sample.to(self.device, torch.float32).contiguous()
         B = sample.shape[0]
         self._row_map = tuple(row_map) if row_map is not None else None
+        self._enc_rows = enc.shape[0]
         self._reuse = self._prepare_reuse(reuse, B, enc)
         self.t_dev.fill_(float(timestep))
         ctrls = self._ctrls()
@@ -363,11 +365,14 @@ class HipUNet:
         Bp = len(rep)                                          # rows per image in this launch
         npass = max(len(p["passes"]) for p in plans if p["passes"] is not None)
         merged = [[] for _ in range(npass)]
+        # cross attention reads K / V rows of the TEXT batch: image i's block starts at i * (text rows per image), which differs from
+        # its latent rows only under the composition hook (R + 1 + P text rows for R + 2 latent rows)
+        Bt = (self._enc_rows // K) if (is_cross and sel is None and self._enc_rows % K == 0) else Bp
         for i, plan in enumerate(plans):
             ps = plan["passes"] if plan["passes"] is not None else [[ops.AttnEntrySpec(b, b) for b in range(Bp)]]
             for p in range(npass):
                 rows = ps[p] if p < len(ps) else [None] * Bp
-                merged[p] += [None if e is None else e.shifted(i * Bp, rep[pr]) for pr, e in enumerate(rows)]
+                merged[p] += [None if e is None else e.shifted(i * Bp, rep[pr], i * Bt) for pr, e in enumerate(rows)]
         out = dict(kind=plans[0]["kind"], passes=merged, needs_cg=any(p["needs_cg"] for p in plans),
                    branch="+".join(sorted({p.get("branch", "") for p in plans})))
         if any("ref_rows" in p for p in plans):
@@ -592,6 +597,7 @@ class HipUNet:
                 C = x.shape[-1]
                 x = ops.conv3x3(x, blk.up[0], blk.up[1], B, H, W, C, upsample=True, out=cat_dst(C, 4 * H * W))
                 H, W = 2 * H, 2 * W
+        C = x.shape[-1]
         x = self._gn(x, self.norm_out, cfg.norm_eps, True)
-        eps = ops.conv3x3(x, self.conv_out[0], self.conv_out[1], B, H, W, x.shape[-1], out_f32=True)
+        eps = ops.conv3x3(x, self.conv_out[0], self.conv_out[1], B, H, W, C, out_f32=True)
         return ops.nhwc_to_nchw_f32(eps, cfg.out_channels, H, W)

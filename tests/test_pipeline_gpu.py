@@ -378,3 +378,65 @@ def test_reference_stream_reuse_is_exact(gpu, graph):
         for j in range(len(sel)):
             assert traj_dev(outs[(True, sel)][j], [t.cpu().numpy() for t in outs[(False, sel)][j]]) < 1e-4, (sel, j)
     assert traj_dev(outs[(True, (0, 1))][0], g[f"{name}_traj"]) < TOL
+
+
+def test_edit_at_768_px_vs_oracle(gpu):
+    """BASELINE.json configs[4]'s resolution (768 x 768 images, 96 x 96 latents, S = 9216 / 2304 / 576 / 144 in the attention layers --
+    the reference itself hard-codes 512, model.py:1347): one FreeFine_generation edit on the tiny topology, 1 + 1 steps with TCA, fp32
+    parity mode and the split-bf16 mode against OraclePipeline; bf16 fast mode bounded.  Also: an original image LARGER than the coarse
+    input is thumbnailed to the coarse input's size, not to 512."""
+    from golden_cases import rect_mask
+    torch.set_num_threads(max(8, min(32, torch.get_num_threads())))
+    H, k = 768, 6
+    rng = np.random.default_rng(0)
+    ori_img, coarse = rng.integers(0, 256, (H, H, 3), dtype=np.uint8), rng.integers(0, 256, (H, H, 3), dtype=np.uint8)
+    ori, tgt, draw = rect_mask(H, H, 50 * k, 76 * k, 24 * k, 50 * k, 255), rect_mask(H, H, 50 * k, 76 * k, 40 * k, 66 * k, 255), rect_mask(H, H, 46 * k, 80 * k, 36 * k, 72 * k, 1)
+    kw = dict(end_step=10, num_step=10, start_step=9, method_type="tca", end_scale=0.5, draw_mask=draw)
+    o_img, _, o_traj = oracle_pipe("tiny").freefine_generation(ori_img, ori, coarse, tgt, "a cup", 7.5, 1.0, seed=42, **kw)
+    for dtype, x3, tol in ((torch.float32, False, TOL), (torch.float32, True, TOL), (torch.bfloat16, False, 0.5)):
+        model = make_pipe(gpu, "tiny", "edit", dtype=dtype, graph=True, x3=x3)
+        img = model.FreeFine_generation(ori_img, ori, coarse, tgt, "a cup", 7.5, 1.0, verbose=True, seed=42, return_intermediates=True, **kw)
+        dev = traj_dev(model.last_intermediates, [t.numpy() for t in o_traj])
+        print(f"768 x 768 edit, {dtype}{' split-bf16' if x3 else ''}: latent L-inf vs oracle {dev:.2e}")
+        assert img.shape == (H, H, 3) and dev < tol
+        if dtype == torch.float32:
+            assert np.abs(img.astype(int) - o_img.astype(int)).max() <= 1
+    assert model._work_size(coarse) == [768, 768] and model.resize_img(np.zeros((1024, 1024, 3), np.uint8), size=model._work_size(coarse)).shape == (768, 768, 3)
+    assert model._work_size(np.zeros((256, 256, 3), np.uint8)) == [512, 512]
+
+
+from golden_cases import oracle_pipe  # noqa: E402
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_image_batched_composition_matches_single(gpu, graph):
+    """FreeFine_cross_image_composition_batch (BASELINE configs[3], R = 2 references, P = 3 prompts incl. the trailing ""): K compositions
+    in one image-major batch == the K single calls, and image 0 (the golden cmp_tca inputs) still matches the REFERENCE's golden
+    trajectory.  The text batch has R + 1 + P rows per image against R + 2 latent rows: the cross-attention K / V rows of image i are
+    offset by its TEXT block."""
+    g = np.load(os.path.join(GOLD, "g5_loops.npz"))
+    ori_img, coarse, img2 = synth_images()
+    oris, tgts = compose_masks()
+    name, kw = CMP_CASES[0]
+    common = dict(end_step=8, num_step=10, start_step=6, dil_factor=9, end_scale=0.5, **kw)
+    cases = [dict(img_lists=[ori_img, img2], ori_mask_lists=oris, tgt_mask_lists=tgts, coarse_input=coarse, guidance_text_list=["a cup", "a dog"]),
+             dict(img_lists=[img2, coarse], ori_mask_lists=oris[::-1], tgt_mask_lists=tgts[::-1], coarse_input=ori_img, guidance_text_list=["a tree", "grass"]),
+             dict(img_lists=[coarse, ori_img], ori_mask_lists=oris, tgt_mask_lists=tgts[::-1], coarse_input=img2, guidance_text_list=["", "a red car"])]
+    seeds = [11, 5, 77]
+    model = make_pipe(gpu, "tiny", "compose", graph=graph)
+    single = []
+    for c, sd in zip(cases, seeds):
+        img = model.FreeFine_cross_image_composition(c["img_lists"], c["ori_mask_lists"], c["tgt_mask_lists"], c["coarse_input"], list(c["guidance_text_list"]),
+                                                     7.5, 1.0, verbose=True, seed=sd, return_intermediates=True, **common)
+        single.append((img, [t.clone() for t in model.last_intermediates]))
+    assert traj_dev(single[0][1], g[f"{name}_traj"]) < TOL
+    for sel in ([0, 1, 2], [0, 1]):
+        for rep in range(2 if graph else 1):
+            imgs = model.FreeFine_cross_image_composition_batch([cases[i] for i in sel], 7.5, 1.0, seeds=[seeds[i] for i in sel], return_intermediates=True,
+                                                                **common)
+            for j, i in enumerate(sel):
+                dev = traj_dev(model.last_intermediates[j], [t.cpu().numpy() if t.ndim == 3 else t[0].cpu().numpy() for t in single[i][1]])
+                print(f"compose batch {sel} graph={graph} rep={rep} image {i}: latent L-inf vs single call {dev:.2e}")
+                assert dev < 1e-4, (sel, i)
+                assert np.abs(imgs[j].astype(int) - single[i][0].astype(int)).max() <= 1
+    assert traj_dev(model.last_intermediates[0], g[f"{name}_traj"]) < TOL
