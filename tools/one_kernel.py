@@ -1,4 +1,5 @@
-"""Run ONE kernel shape repeatedly (for rocprofv3 --pmc passes).  python tools/one_kernel.py conv 64 320 320 | gemm M K N | geglu M K N | attn S C heads passes"""
+"""Run ONE kernel shape repeatedly (for rocprofv3 --pmc passes).  python tools/one_kernel.py conv 64 320 320 | gemm M K N | geglu M K N | attn S C heads passes
+ONE_B = batch rows (conv / attn); ONE_MODE = bf16 (default) | x3 (split-bf16: fp32 activations, FFN_BF16X3 weights / attn_x3_kernel)"""
 import os
 import sys
 
@@ -8,7 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from freefine_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-dt = torch.bfloat16
+X3 = os.environ.get("ONE_MODE", "bf16") == "x3"
+dt = torch.float32 if X3 else torch.bfloat16
 g = torch.Generator().manual_seed(0)
 rnd = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(dt).to(dev)
 kind = sys.argv[1]
@@ -16,20 +18,23 @@ B = int(os.environ.get("ONE_B", 4))
 if kind == "conv":
     hw, cin, cout = map(int, sys.argv[2:5])
     x = rnd(B, hw * hw, cin)
-    w = ops.pack_conv3x3(rnd(cout, cin, 3, 3, scale=(9 * cin) ** -0.5), dt)
+    w = ops.pack_conv3x3(rnd(cout, cin, 3, 3, scale=(9 * cin) ** -0.5), dt, x3=X3)
     b = torch.zeros(cout, device=dev)
-    fn = lambda: ops.conv3x3(x, w, b, B, hw, hw, cin)
+    xin = ops.split_pair(x, cin) if X3 else x            # (the UNet's norms hand the convolutions pair rows)
+    fn = lambda: ops.conv3x3(xin, w, b, B, hw, hw, cin)
 elif kind == "geglu":
     M, K, N = map(int, sys.argv[2:5])       # N = packed hidden | gate columns
     x = rnd(M, K)
-    wp, bp = ops.pack_geglu(rnd(N, K, scale=K ** -0.5), torch.zeros(N, device=dev), dt)
-    out = torch.empty(M, N // 2, dtype=dt, device=dev)
-    fn = lambda: ops.linear(x, wp, bp, K=K, geglu=True, out=out)
+    wp, bp = ops.pack_geglu(rnd(N, K, scale=K ** -0.5), torch.zeros(N, device=dev), dt, x3=X3)
+    out = None if X3 else torch.empty(M, N // 2, dtype=dt, device=dev)
+    xin = ops.split_pair(x, K) if X3 else x
+    fn = lambda: ops.linear(xin, wp, bp, K=K, geglu=True, out=out, out_pair=X3)
 elif kind == "gemm":
     M, K, N = map(int, sys.argv[2:5])
     x = rnd(M, K)
-    w = ops.pack_linear(rnd(N, K, scale=K ** -0.5), dt)
-    fn = lambda: ops.linear(x, w, None)
+    w = ops.pack_linear(rnd(N, K, scale=K ** -0.5), dt, x3=X3)
+    xin = ops.split_pair(x, K) if X3 else x
+    fn = lambda: ops.linear(xin, w, None, K=K)
 else:
     S, C, heads, passes = map(int, sys.argv[2:6])
     q, k, vt = rnd(B, S, C), rnd(B, S, C), rnd(B, C, S)
@@ -38,7 +43,7 @@ else:
     cg = torch.tensor([0.5], device=dev)
     P = None if passes == 1 else [[ops.AttnEntrySpec(b, b | 1, 0.0, 1.0, kmask=km, qsel=qs, flags=1) for b in range(B)],
                                   [ops.AttnEntrySpec(b, b, 1.0, -1.0) for b in range(B)]]
-    fn = lambda: ops.attention(q, k, vt, heads, (C // heads) ** -0.5, P, w_dev=cg)
+    fn = lambda: ops.attention(q, k, vt, heads, (C // heads) ** -0.5, P, w_dev=cg, x3=X3)
 for _ in range(10):
     fn()
 torch.cuda.synchronize()

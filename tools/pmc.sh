@@ -15,7 +15,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "igemm" in k or "attn" in k or "gn_" in k:
+        if "igemm" in k or "attn" in k or "gn_" in k or "layernorm" in k or "split_pair" in k:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 dur = collections.defaultdict(list)
 for f in glob.glob(out + "/p1/*/*kernel_trace.csv"):
