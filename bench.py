@@ -270,7 +270,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-parity", action="store_true", help="skip the parity-mode leg (f32 throughput + the headline mode's latent deviation)")
     ap.add_argument("--parity-modes", default="f32,bf16x3", help="comma list; the first one is the reference of the deviation figures")
-    ap.add_argument("--parity-batch", type=int, default=4)
+    ap.add_argument("--parity-batch", type=int, default=8)
     args = ap.parse_args()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))

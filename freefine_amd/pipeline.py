@@ -71,7 +71,7 @@ class FreeFinePipeline:
         seeded random weights of that architecture (no checkpoints exist in the build environment).
         torch_dtype float32 -> exact-fp32 parity mode; float16/bfloat16 -> bf16 MFMA fast mode; float32 with x3=True -> the
         split-bf16 mode (fp32 activations, every UNet GEMM on three bf16 MFMAs per product term: fp32-level results at several
-        times the fp32-MFMA rate; the VAE bracket stays exact fp32).
+        times the fp32-MFMA rate; the VAE bracket runs in the same mode).
         In a torch.distributed job (`broadcast="auto"`: whenever a process group with more than one rank is initialised) only
         rank 0 reads / generates the UNet and VAE weights; the other ranks receive them over RCCL straight into device memory
         (freefine_amd.dist.broadcast_state; bf16 payload for the matrices in fast mode) -- the reference has every rank read
@@ -128,7 +128,7 @@ class FreeFinePipeline:
         validate_state_dict(ustate, unet_param_shapes(ucfg), "unet")
         validate_state_dict(vstate, vae_param_shapes(vcfg), "vae")
         unet = HipUNet(ucfg, ustate, dtype=dtype, device=device, x3=x3)
-        vae = HipVAE(vcfg, vstate, dtype=dtype, device=device)
+        vae = HipVAE(vcfg, vstate, dtype=dtype, device=device, x3=x3)
         return cls(unet, vae, tokenizer, text_encoder, scheduler or DDIMScheduler(), device)
 
     def to(self, device=None, *a, **k):

@@ -18,7 +18,12 @@ class _O:
 
 
 class HipVAE:
-    def __init__(self, cfg: VAEConfig, state, dtype=torch.bfloat16, device="cuda:0"):
+    def __init__(self, cfg: VAEConfig, state, dtype=torch.bfloat16, device="cuda:0", x3=False):
+        """x3 (with dtype float32): split-bf16 mode -- fp32 activations, every conv / Linear an FFN_BF16X3 GEMM, norms write the pair
+        form; the mid-block attention's two activation-by-activation products stay on the exact-fp32 GEMM (their "weights" are
+        activations, which have no packed [hi | lo | hi] form)."""
+        assert not x3 or dtype == torch.float32
+        self.x3 = bool(x3)
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
         self.G = cfg.norm_num_groups
         self._pack(state)
@@ -31,13 +36,13 @@ class HipVAE:
         if cout_pad and cout_pad > w.shape[0]:
             w = torch.cat([w, torch.zeros(cout_pad - w.shape[0], *w.shape[1:], device=self.device)], 0)
             b = torch.cat([b, torch.zeros(cout_pad - b.shape[0], device=self.device)], 0)
-        return ops.pack_conv3x3(w, self.dtype, cin_pad), b.contiguous(), (cin_pad or w.shape[1])
+        return ops.pack_conv3x3(w, self.dtype, cin_pad, self.x3), b.contiguous(), (cin_pad or w.shape[1])
 
     def _lin(self, st, name):
         w, b = st[name + ".weight"].float().to(self.device), st[name + ".bias"].float().to(self.device)
         if w.ndim == 4:
             w = w.reshape(w.shape[0], w.shape[1])
-        return ops.pack_linear(w, self.dtype), b.contiguous(), w.shape[1]
+        return ops.pack_linear(w, self.dtype, self.x3), b.contiguous(), w.shape[1]
 
     def _res(self, st, p):
         r = _O()
@@ -62,7 +67,7 @@ class HipVAE:
 
     def _pack(self, st):
         cfg = self.cfg
-        e = ops.epc(self.dtype)
+        e = 8 if self.x3 else ops.epc(self.dtype)
         s = cfg.scaling_factor
         n = len(cfg.block_out_channels)
         self.img_cp = (cfg.in_channels + e - 1) // e * e
@@ -80,13 +85,13 @@ class HipVAE:
         self.lat_cp = (2 * lc + e - 1) // e * e
         qw, qb = st["quant_conv.weight"].float().reshape(2 * lc, 2 * lc), st["quant_conv.bias"].float()
         # only the mean rows are needed (latent_dist.mean, model.py:267); scale folded in; N padded to a multiple of 4
-        self.quant = (ops.pack_linear((qw[:lc] * s).to(self.device), self.dtype), (qb[:lc] * s).to(self.device).contiguous(), 2 * lc)
+        self.quant = (ops.pack_linear((qw[:lc] * s).to(self.device), self.dtype, self.x3), (qb[:lc] * s).to(self.device).contiguous(), 2 * lc)
         self.zin_cp = (lc + e - 1) // e * e
         pw = torch.zeros(self.zin_cp, self.zin_cp)
         pw[:lc, :lc] = st["post_quant_conv.weight"].float().reshape(lc, lc) / s          # decode(z / 0.18215): 1/s folded in
         pb = torch.zeros(self.zin_cp)
         pb[:lc] = st["post_quant_conv.bias"].float()
-        self.post_quant = (ops.pack_linear(pw.to(self.device), self.dtype), pb.to(self.device).contiguous(), self.zin_cp)
+        self.post_quant = (ops.pack_linear(pw.to(self.device), self.dtype, self.x3), pb.to(self.device).contiguous(), self.zin_cp)
         self.dec_in = self._conv(st, "decoder.conv_in", self.zin_cp)
         self.dec_mid = self._mid(st, "decoder.mid_block")
         self.dec_up = []
@@ -100,7 +105,7 @@ class HipVAE:
 
     # ------------------------------------------------------------------------------------------------------------
     def _gn(self, x, gb, silu):
-        return ops.groupnorm(x, gb[0], gb[1], self.G, 1e-6, silu=silu)
+        return ops.groupnorm(x, gb[0], gb[1], self.G, 1e-6, silu=silu, pair=self.x3)
 
     def _resblock(self, r, x, B, H, W):
         cin = x.shape[-1]
@@ -148,8 +153,9 @@ class HipVAE:
                 x = ops.conv3x3(x, blk.down[0], blk.down[1], B, H, W, C, stride=2, pad=0, Hout=H // 2, Wout=W // 2)
                 H, W = H // 2, W // 2
         x = self._midblock(self.enc_mid, x, B, H, W)
+        C = x.shape[-1]
         x = self._gn(x, self.enc_norm, True)
-        x = ops.conv3x3(x, self.enc_out[0], self.enc_out[1], B, H, W, x.shape[-1])
+        x = ops.conv3x3(x, self.enc_out[0], self.enc_out[1], B, H, W, C)
         z = ops.linear(x, self.quant[0], self.quant[1], K=self.quant[2], out_f32=True)     # [B,HW,4] fp32, already * 0.18215
         return ops.nhwc_to_nchw_f32(z, self.cfg.latent_channels, H, W)
 
@@ -169,6 +175,7 @@ class HipVAE:
                 C = x.shape[-1]
                 x = ops.conv3x3(x, blk.up[0], blk.up[1], B, H, W, C, upsample=True)
                 H, W = 2 * H, 2 * W
+        C = x.shape[-1]
         x = self._gn(x, self.dec_norm, True)
-        x = ops.conv3x3(x, self.dec_out[0], self.dec_out[1], B, H, W, x.shape[-1])         # [B,HW,4] (3 real channels)
+        x = ops.conv3x3(x, self.dec_out[0], self.dec_out[1], B, H, W, C)                   # [B,HW,4] (3 real channels)
         return ops.nhwc_to_image(x, H, W)

@@ -152,8 +152,8 @@ def test_vae_bracket_vs_oracle(gpu):
     from freefine_amd.vae import HipVAE
     from oracle import sd_vae
     ov = sd_vae.init_vae(sd_vae.vae_config("tiny"), seed=1)
-    for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, 5e-2)):
-        hv = HipVAE(VAEConfig.preset("tiny"), ov.state_dict(), dtype=dtype, device=gpu)
+    for dtype, x3, tol in ((torch.float32, False, 1e-4), (torch.float32, True, 1e-4), (torch.bfloat16, False, 5e-2)):
+        hv = HipVAE(VAEConfig.preset("tiny"), ov.state_dict(), dtype=dtype, device=gpu, x3=x3)
         img = np.random.default_rng(5).integers(0, 256, (2, 64, 96, 3), dtype=np.uint8)
         x = (torch.from_numpy(img).float() / 127.5 - 1).permute(0, 3, 1, 2)
         ref = ov.encode_mean(x) * 0.18215
@@ -323,13 +323,13 @@ def test_vae_full_size_vs_oracle(gpu):
     x = (torch.from_numpy(img).float() / 127.5 - 1).permute(0, 3, 1, 2)
     ref = ov.encode_mean(x) * 0.18215
     dref = (ov.decode(ref / 0.18215) / 2 + 0.5).clamp(0, 1)
-    for dtype, tol in ((torch.float32, 2e-4), (torch.bfloat16, 5e-2)):
-        hv = HipVAE(VAEConfig.preset("sd"), ov.state_dict(), dtype=dtype, device=gpu)
+    for dtype, x3, tol in ((torch.float32, False, 2e-4), (torch.float32, True, 2e-4), (torch.bfloat16, False, 5e-2)):
+        hv = HipVAE(VAEConfig.preset("sd"), ov.state_dict(), dtype=dtype, device=gpu, x3=x3)
         out = hv.encode_mean_scaled(img_u8=torch.from_numpy(img)).cpu()
         e_enc = ((out - ref).abs().max() / ref.abs().max()).item()
         dout = hv.decode_image(ref.to(gpu)).cpu()
         e_dec = (dout - dref).abs().max().item()
-        print(f"SD VAE @512^2 {dtype}: encode max |diff| / max |ref| = {e_enc:.2e}, decode max |diff| (image in [0,1]) = {e_dec:.2e}")
+        print(f"SD VAE @512^2 {dtype}{' split-bf16' if x3 else ''}: encode max |diff| / max |ref| = {e_enc:.2e}, decode max |diff| (image in [0,1]) = {e_dec:.2e}")
         assert out.shape == ref.shape == (1, 4, 64, 64) and dout.shape == dref.shape == (1, 3, 512, 512)
         assert e_enc < tol and e_dec < 2 * tol
         del hv
