@@ -81,7 +81,7 @@ def build_model(args, device, rank, world):
         ust, vst = synthetic_state(unet_param_shapes(ucfg), 0), synthetic_state(vae_param_shapes(vcfg), 1)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = FreeFinePipeline.from_state(ucfg, ust, vcfg, vst, ByteTokenizer(), SyntheticTextEncoder(ucfg.cross_attention_dim), None, dtype, device,
-                                        x3=args.dtype == "bf16x3")
+                                        x3=args.dtype == "bf16x3", fp8_conv=bool(getattr(args, "fp8_conv", False)) and args.dtype == "bf16")
     model.scheduler = DDIMScheduler.from_config(model.scheduler.config)
     controller = Attention_Modulator(start_layer=10)
     model.controller = controller
@@ -164,6 +164,7 @@ def parity_leg(args, device, model_fast):
     import copy
     out = {"tolerance_latent_linf": 1e-3, "modes": {}}
     ref_traj = None
+    global _F32_TRAJ
     for mode in args.parity_modes.split(","):
         a = copy.copy(args)
         a.dtype, a.batch = mode, args.parity_batch
@@ -179,6 +180,7 @@ def parity_leg(args, device, model_fast):
         traj = torch.stack([t.float() for t in m.last_intermediates]).cpu()
         if ref_traj is None:
             ref_traj = traj        # the first mode listed (f32) is the reference of the deviation figures
+            _F32_TRAJ = traj
             model_fast.FreeFine_generation(ori_img, ori_mask, coarse, tgt_mask, "a photo of a cup", 7.5, 1.0, **kw)
             ft = torch.stack([t.float() for t in model_fast.last_intermediates]).cpu()
             d = (ft - ref_traj).abs().flatten(1).max(dim=1).values
@@ -206,6 +208,36 @@ def parity_leg(args, device, model_fast):
         del m
         torch.cuda.empty_cache()
     return out
+
+
+_F32_TRAJ = None
+
+
+def fp8_leg(args, device):
+    """the bf16 fast mode with e4m3 ResBlock convolutions (FFN_FP8; north star: "MFMA (bf16/fp8)"): REPORTED beside the headline, never as
+    parity -- throughput at the headline's batch on one stream, and its latent deviation from the f32 run of the parity leg"""
+    import copy
+    a = copy.copy(args)
+    a.fp8_conv, a.dtype = True, "bf16"
+    m = build_model(a, device, 0, 1)
+    rec = {"unit": "images/s", "images_per_unet_batch": args.batch, "concurrent_streams": 1, "steps": 1,
+           "what": "bf16 fast mode with the two 3x3 convolutions of every ResBlock on e4m3 operands (55 % of the UNet FLOPs; v_mfma_f32_16x16x32_fp8_fp8)"}
+    if _F32_TRAJ is not None:
+        ori_img, ori_mask, coarse, tgt_mask, draw = synth_inputs(0)
+        m.FreeFine_generation(ori_img, ori_mask, coarse, tgt_mask, "a photo of a cup", 7.5, 1.0, end_step=args.num_step, num_step=args.num_step,
+                              start_step=args.start_step, method_type="tca", verbose=False, seed=42, draw_mask=draw, end_scale=0.0, return_intermediates=True)
+        d = (torch.stack([t.float() for t in m.last_intermediates]).cpu() - _F32_TRAJ).abs().flatten(1).max(dim=1).values
+        rec["latent_linf_vs_f32"] = {"final": round(d[-1].item(), 5), "max_over_steps": round(d.max().item(), 5)}
+    for i in range(2):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        edit_once(m, a, 8000 + i)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+    rec["value"] = round(args.batch / dt, 4)
+    del m
+    torch.cuda.empty_cache()
+    return rec
 
 
 def cpu_baseline_leg(args):
@@ -268,6 +300,8 @@ def main():
     ap.add_argument("--no-ref-layout", dest="no_ref_layout", action="store_true", help="skip the extra one-image-per-UNet-batch measurement")
     ap.add_argument("--cpu-skip-vae", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--fp8-conv", dest="fp8_conv", action="store_true", help="bf16 mode with e4m3 ResBlock convolutions (FFN_FP8) as the timed configuration")
+    ap.add_argument("--no-fp8-leg", dest="no_fp8_leg", action="store_true", help="skip the extra fp8-convolution measurement of the default run")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity-mode leg (f32 throughput + the headline mode's latent deviation)")
     ap.add_argument("--parity-modes", default="f32,bf16x3", help="comma list; the first one is the reference of the deviation figures")
     ap.add_argument("--parity-batch", type=int, default=8)
@@ -368,6 +402,7 @@ def main():
                                    f"(start_step={args.start_step}: per image {n} inversion forwards x 2 rows + {n} guided forwards x 4 rows, TCA blocks "
                                    f"10-15, masked CFG 7.5, eta=1) + VAE bracket; {args.batch} independent edits per UNet batch x "
                                    f"{args.concurrent} HIP streams; seeded random weights",
+                       "fp8_convolutions": bool(args.fp8_conv and args.dtype == "bf16"),
                        "images_per_gpu_per_step": args.concurrent * args.batch, "concurrent_streams": args.concurrent,
                        "images_per_unet_batch": args.batch, "unet_batch": 4 * args.batch, "hip_graph": not args.no_graph,
                        "exact_row_dedup": model.dedup_rows and "on: the duplicated reference row of the CFG batch is evaluated once (3 physical rows), outputs unchanged",
@@ -418,6 +453,15 @@ def main():
                     f.write(f"{k}\t{c}\t{ms:.3f}\t{gf:.1f}\t{gbs:.1f}\n")
         if not args.no_parity and world == 1 and args.dtype != "f32":
             line["parity"] = parity_leg(args, device, model)
+        if not args.no_fp8_leg and not args.fp8_conv and world == 1 and args.dtype == "bf16":
+            # the same number for the plain bf16 engine on ONE stream, so that the fp8 figure has its like-for-like neighbour
+            rec = fp8_leg(args, device)
+            t0 = time.time()
+            with torch.cuda.stream(streams[0]):
+                edit_once(models[0], args, 9000)
+            streams[0].synchronize()
+            rec["bf16_same_layout"] = round(args.batch / (time.time() - t0), 4)
+            line["fp8_conv"] = rec
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline_leg(args)
         print(json.dumps(line), flush=True)

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FREEFINE_HIP_LIB") or os.path.join(_HERE, "libfreefine_hip.so")   # env override: A/B builds of the same ABI
 
-FFN_F32, FFN_BF16, FFN_BF16X3 = 0, 1, 2
+FFN_F32, FFN_BF16, FFN_BF16X3, FFN_FP8 = 0, 1, 2, 3
 IG_OUT_SILU, IG_OUT_F32, IG_GEGLU, IG_OUT_TRANSPOSED, IG_OUT_PAIR = 1, 2, 4, 8, 16
 ATT_MAXP, ATT_MAXB = 4, 16
 ATT_HEAD_RULE, ATT_UNIFORM_SEL1, ATT_UNIFORM_SEL0 = 1, 2, 4
@@ -26,7 +26,7 @@ class IgemmDesc(C.Structure):
         ("stride", C.c_int), ("pad", C.c_int), ("upsample", C.c_int),
         ("flags", C.c_int), ("alpha", C.c_float), ("conv", C.c_int),
         ("splitk", C.c_int), ("ws", C.c_void_p), ("ws_bytes", C.c_long),
-        ("a_lo", C.c_int), ("x3", C.c_int),
+        ("a_lo", C.c_int), ("x3", C.c_int), ("f8", C.c_int),
     ]
 
 
@@ -74,6 +74,7 @@ SYMBOLS = {
     "ffn_device_info": (_i, [_i, C.c_char_p, _i]),
     "ffn_igemm": (_i, [_vp, _i, C.POINTER(IgemmDesc)]),
     "ffn_split_pair": (_i, [_vp, _vp, _vp, _l, _i, _i]),
+    "ffn_groupnorm_f8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _f, _vp, _vp, _vp]),
     "ffn_attn": (_i, [_vp, _i, C.POINTER(AttnDesc)]),
     "ffn_attn_kernel_name": (_i, [_i, C.POINTER(AttnDesc), C.c_char_p, _i]),
     "ffn_igemm_tune": (_i, [_vp, _i, C.POINTER(IgemmDesc)]),

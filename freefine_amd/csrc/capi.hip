@@ -264,7 +264,8 @@ static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn, int splitk = 1) {
     if (splitk > 1) {       // split-K: raw fp32 slabs + igemm_splitk_reduce_kernel (which applies every plain epilogue option)
         if (!can_split(d) || (d.K / 64) % splitk != 0 || d.K / 64 / splitk < 2 || (long)splitk * d.M * d.N * 4 > d.ws_bytes || (long)splitk * d.M * d.N * 4 >= lim) return false;
     } else {
-        if (d.alpha != 1.0f || (d.flags & ~(FFN_IG_GEGLU | (d.x3 ? (FFN_IG_OUT_F32 | FFN_IG_OUT_PAIR) : 0)))) return false;
+        if ((d.alpha != 1.0f && !d.f8) || (d.flags & ~(FFN_IG_GEGLU | (d.x3 ? (FFN_IG_OUT_F32 | FFN_IG_OUT_PAIR) : 0)))) return false;
+        if (d.f8 && (!d.conv || (d.flags & FFN_IG_GEGLU))) return false;
         if (d.x3 && ((d.flags & FFN_IG_GEGLU) != 0) != ((d.flags & FFN_IG_OUT_PAIR) != 0)) return false;      // the split-bf16 GEGLU tile writes the pair form, nothing else does
         if ((d.flags & FFN_IG_GEGLU) && bn != 256) return false;
         if (d.rowbias && d.rows_per_batch < 128) return false;      // a wave's rows (bm / 2) may straddle two images, not three
@@ -305,10 +306,10 @@ static int halo_bytes_for(const ffn_igemm_desc& d, int bm) {
 }
 // X3 (split-bf16, FFN_BF16X3) problems run the generic 64x64 / 128x64 / 128x128 tiles (recomputing loader) and the ping-pong tiles
 static bool x3_cfg(int cfg) { return cfg == CFG_64x64 || cfg == CFG_128x64 || cfg == CFG_128x128_8 || is_pp_cfg(cfg); }
-template <int AMODE, bool X3 = false>
+template <int AMODE, bool X3 = false, bool F8 = false>
 static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) {
     const IgCfgInfo& c = kCfg[ch.cfg];
-    if (X3 && !x3_cfg(ch.cfg)) return fail(FFN_EINVAL, "igemm: configuration %d is not built for split-bf16 problems", ch.cfg);
+    if ((X3 || F8) && !x3_cfg(ch.cfg)) return fail(FFN_EINVAL, "igemm: configuration %d is not built for split-bf16 / fp8 problems", ch.cfg);
     const int ntiles = ((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn);
     const int lds = 2 * (c.bm + c.bn) * 128, threads = 64 * c.nwm * c.nwn;
     int rc = FFN_OK;
@@ -321,6 +322,9 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
         if constexpr (X3) {                                                                                                         \
             if constexpr (ID == CFG_64x64 || ID == CFG_128x64 || ID == CFG_128x128_8)                                               \
                 rc = launch_igemm_kernel(igemm_glds_kernel<bf16, BM_, BN_, AMODE, true, 2, WM_, WN_, false, true>, lds, s, d, ntiles, ch.splitk, threads, true); \
+        } else if constexpr (F8) {                                                                                                  \
+            if constexpr (AMODE == AMODE_CONV3 && (ID == CFG_64x64 || ID == CFG_128x64 || ID == CFG_128x128_8))                     \
+                rc = launch_igemm_kernel(igemm_glds_kernel<bf16, BM_, BN_, AMODE, true, 2, WM_, WN_, false, false, true>, lds, s, d, ntiles, ch.splitk, threads, true); \
         } else {                                                                                                                    \
             rc = fastk ? launch_igemm_kernel(igemm_glds_kernel<bf16, BM_, BN_, AMODE, true, 2, WM_, WN_, true>, lds, s, d, ntiles, ch.splitk, threads, true)  \
                        : launch_igemm_kernel(igemm_glds_kernel<bf16, BM_, BN_, AMODE, true, 2, WM_, WN_, false>, lds, s, d, ntiles, ch.splitk, threads, true); \
@@ -347,7 +351,7 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
             (void)hipGetLastError();
 #define FFN_PP_LAUNCH(BM_, BN_, RES_, GEGLU_)                                              \
     do {                                                                                   \
-        auto kern = igemm_pp_kernel<BM_, BN_, AMODE, RES_, GEGLU_, false, false, X3>;      \
+        auto kern = igemm_pp_kernel<BM_, BN_, AMODE, RES_, (GEGLU_) && !F8, false, false, X3, F8>;      \
         if ((rc = set_lds(kern, pplds))) return rc;                                        \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pplds, s, d, 1);                   \
     } while (0)
@@ -369,7 +373,7 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
     } while (0)
 #define FFN_PP_SPLIT(BM_, BN_)                                                             \
     do {                                                                                   \
-        auto kern = igemm_pp_kernel<BM_, BN_, AMODE, false, false, true, false, X3>;       \
+        auto kern = igemm_pp_kernel<BM_, BN_, AMODE, false, false, true, false, X3, F8>;   \
         if ((rc = set_lds(kern, pplds))) return rc;                                        \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pplds, s, d, ch.splitk);           \
     } while (0)
@@ -395,7 +399,7 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
         case CFG_H_256x128:
         case CFG_H_256x256:
         case CFG_H_128x128:
-            if constexpr (AMODE == AMODE_CONV3 && !X3) {
+            if constexpr (AMODE == AMODE_CONV3 && !X3 && !F8) {
                 const int hb = halo_bytes_for(d, c.bm);
                 if (hb <= 0 || ch.splitk != 1) return fail(FFN_EINVAL, "igemm: halo kernel not applicable");
                 const int hlds = 2 * hb + 2 * c.bn * 128;
@@ -451,7 +455,7 @@ static TuneKey tune_key(const ffn_igemm_desc& d) {
     if (d.conv) { k.Cin = d.Cin; k.Hin = d.Hin; k.Win = d.Win; k.stride = d.stride; k.upsample = d.upsample; k.pad = d.pad; k.Hout = d.Hout; k.Wout = d.Wout; }
     k.Kpad = d.Kpad;
     k.ldr = d.residual ? d.ldr : 0;
-    k.dtype = d.x3 ? FFN_BF16X3 : FFN_BF16;
+    k.dtype = d.x3 ? FFN_BF16X3 : (d.f8 ? FFN_FP8 : FFN_BF16);
     k.ptrs = (d.bias ? 1 : 0) | (d.rowbias ? 2 : 0) | (d.residual ? 4 : 0) | (d.ws && d.ws_bytes > 0 ? 8 : 0);
     const long per = (long)d.M * d.N * 4;
     k.wslabs = d.ws ? (int)(d.ws_bytes / per > 1024 ? 1024 : d.ws_bytes / per) : 0;      // how many split-K slabs the workspace holds
@@ -492,7 +496,7 @@ static IgChoice heuristic_choice(const ffn_igemm_desc& d) {
     igemm_exec_cfg(FFN_BF16, d, bm, bn, sk, &ns, &nw);
     int cfg = CFG_64x64;
     if (bm == 128 && bn == 64) cfg = CFG_128x64;
-    if (bm == 128 && bn == 128) cfg = (nw == 16 && !d.x3) ? CFG_128x128_16 : CFG_128x128_8;
+    if (bm == 128 && bn == 128) cfg = (nw == 16 && !d.x3 && !d.f8) ? CFG_128x128_16 : CFG_128x128_8;
     return IgChoice{cfg, sk};
 }
 static int candidates_for(const ffn_igemm_desc& d, IgChoice* out, int cap) {
@@ -503,7 +507,7 @@ static int candidates_for(const ffn_igemm_desc& d, IgChoice* out, int cap) {
     const long per = (long)d.M * d.N * 4;
     for (int cfg = 0; cfg < CFG_COUNT; ++cfg) {
         const IgCfgInfo& c = kCfg[cfg];
-        if (d.x3 && !x3_cfg(cfg)) continue;
+        if ((d.x3 || d.f8) && !x3_cfg(cfg)) continue;
         if ((cfg == CFG_128x320 || cfg == CFG_128x160 || cfg == CFG_192x320) && (d.flags & FFN_IG_GEGLU)) continue;   // odd number of column blocks per wave
         if (is_halo_cfg(cfg)) {
             const int hb = halo_bytes_for(d, c.bm);
@@ -563,14 +567,14 @@ extern "C" int ffn_igemm_force_config(int cfg) {
     g_force_cfg = (cfg >= 0 && cfg < CFG_COUNT) ? cfg : -1;
     return prev;
 }
-template <int AMODE, bool X3 = false>
+template <int AMODE, bool X3 = false, bool F8 = false>
 static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
     if (g_force_cfg >= 0) {
         IgChoice cand[40];
         const int nc = candidates_for(d, cand, 40);
         for (int i = 0; i < nc; ++i)
-            if (cand[i].cfg == g_force_cfg) return launch_bf16_cfg<AMODE, X3>(s, d, cand[i]);
-        return launch_bf16_cfg<AMODE, X3>(s, d, heuristic_choice(d));     // not valid for this problem
+            if (cand[i].cfg == g_force_cfg) return launch_bf16_cfg<AMODE, X3, F8>(s, d, cand[i]);
+        return launch_bf16_cfg<AMODE, X3, F8>(s, d, heuristic_choice(d));     // not valid for this problem
     }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
@@ -591,25 +595,25 @@ static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
                 if (ok) it->second.validated = true;
                 else g_tuned.erase(it), it = g_tuned.end();
             }
-            if (it != g_tuned.end()) return launch_bf16_cfg<AMODE, X3>(s, d, it->second.ch);
+            if (it != g_tuned.end()) return launch_bf16_cfg<AMODE, X3, F8>(s, d, it->second.ch);
         }
     }
-    if (!tune_enabled() || cap != hipStreamCaptureStatusNone || aliased) return launch_bf16_cfg<AMODE, X3>(s, d, heuristic_choice(d));
+    if (!tune_enabled() || cap != hipStreamCaptureStatusNone || aliased) return launch_bf16_cfg<AMODE, X3, F8>(s, d, heuristic_choice(d));
     std::lock_guard<std::mutex> lk(g_tune_mu);       // one tuning at a time
     IgChoice cand[40];
     const int nc = candidates_for(d, cand, 40);
     hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return launch_bf16_cfg<AMODE, X3>(s, d, cand[0]);
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return launch_bf16_cfg<AMODE, X3, F8>(s, d, cand[0]);
     IgChoice best = cand[0];
     float best_ms = 1e30f;
     const int reps = 3;
     for (int i = 0; i < nc; ++i) {
-        int rc = launch_bf16_cfg<AMODE, X3>(s, d, cand[i]);      // warm (LDS opt-in, code load)
+        int rc = launch_bf16_cfg<AMODE, X3, F8>(s, d, cand[i]);      // warm (LDS opt-in, code load)
         if (rc) continue;
         float ms = 1e30f;
         for (int round = 0; round < 2 && !rc; ++round) {       // min of two timed groups: one noisy group must not pick the configuration
             (void)hipEventRecord(e0, s);
-            for (int r = 0; r < reps && !rc; ++r) rc = launch_bf16_cfg<AMODE, X3>(s, d, cand[i]);
+            for (int r = 0; r < reps && !rc; ++r) rc = launch_bf16_cfg<AMODE, X3, F8>(s, d, cand[i]);
             (void)hipEventRecord(e1, s);
             if (rc || hipEventSynchronize(e1) != hipSuccess) { rc = rc ? rc : FFN_EHIP; break; }
             float t = 0.f;
@@ -626,7 +630,7 @@ static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
     if (verbose)
         fprintf(stderr, "[ffn tune] %s M=%d N=%d K=%d flags=%d -> %dx%d split %d (%.1f us, %d candidates)\n", d.conv ? "conv" : "dense", d.M, d.N,
                 d.K, d.flags, kCfg[best.cfg].bm, kCfg[best.cfg].bn, best.splitk, best_ms * 1e3f / reps, nc);
-    return launch_bf16_cfg<AMODE, X3>(s, d, best);       // the output now holds the winner's result
+    return launch_bf16_cfg<AMODE, X3, F8>(s, d, best);       // the output now holds the winner's result
 }
 // ---- the tuned table as data: export / import (persist it across processes, broadcast rank 0's table so that every rank of a
 // sharded run launches the same configurations -- bf16 results then are bit-identical across ranks)
@@ -689,19 +693,20 @@ static bool tuned_lookup(const ffn_igemm_desc& d, IgChoice* ch) {
 
 static bool pp_trans_tile(const ffn_igemm_desc& d, int* bm, int* bn);
 static ffn_igemm_desc x3_view(const ffn_igemm_desc& d);
+static ffn_igemm_desc f8_view(const ffn_igemm_desc& d);
 extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d0, char* buf, int len) {
     REQUIRE(d0 && buf && len > 0, "igemm_kernel_name: null argument");
     int bm, bn, sk, ns, nw;
     IgChoice ch;
-    const bool x3 = dtype == FFN_BF16X3;
-    const ffn_igemm_desc dd = x3 ? x3_view(*d0) : *d0;
+    const bool x3 = dtype == FFN_BF16X3, f8 = dtype == FFN_FP8;
+    const ffn_igemm_desc dd = x3 ? x3_view(*d0) : (f8 ? f8_view(*d0) : *d0);
     const ffn_igemm_desc* d = &dd;
     if (x3 && (d->flags & FFN_IG_OUT_TRANSPOSED)) {
         igemm_plan_for(FFN_BF16, *d, &bm, &bn, &sk);
-        snprintf(buf, len, "void igemm_glds_kernel<bf16, %d, %d, 0, false, 2, 2, 2, false, true>(ffn_igemm_desc)", bm, bn);
+        snprintf(buf, len, "void igemm_glds_kernel<bf16, %d, %d, 0, false, 2, 2, 2, false, true, false>(ffn_igemm_desc)", bm, bn);
         return FFN_OK;
     }
-    if ((dtype == FFN_BF16 || x3) && !(d->flags & FFN_IG_OUT_TRANSPOSED)) {      // the tuned (or, untuned, rule-based) bf16 configuration
+    if ((dtype == FFN_BF16 || x3 || f8) && !(d->flags & FFN_IG_OUT_TRANSPOSED)) {      // the tuned (or, untuned, rule-based) bf16 configuration
         if (!tuned_lookup(*d, &ch)) ch = heuristic_choice(*d);
         const IgCfgInfo& c = kCfg[ch.cfg];
         if (is_halo_cfg(ch.cfg)) {
@@ -710,18 +715,18 @@ extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d0, char* 
         }
         if (is_pp_cfg(ch.cfg)) {
             const bool split = ch.splitk > 1;
-            snprintf(buf, len, "void igemm_pp_kernel<%d, %d, %d, %s, %s, %s, false, %s>(ffn_igemm_desc, int)", c.bm, c.bn, d->conv ? 1 : 0,
+            snprintf(buf, len, "void igemm_pp_kernel<%d, %d, %d, %s, %s, %s, false, %s, %s>(ffn_igemm_desc, int)", c.bm, c.bn, d->conv ? 1 : 0,
                      (!split && d->residual) ? "true" : "false", (!split && (d->flags & FFN_IG_GEGLU)) ? "true" : "false", split ? "true" : "false",
-                     x3 ? "true" : "false");
+                     x3 ? "true" : "false", f8 ? "true" : "false");
             return FFN_OK;
         }
-        const bool fastk = !x3 && (d->conv ? d->Cin % 64 == 0 : d->K % 64 == 0) && (long)d->K * 2 + 256 <= (long)sizeof(g_zero_page);
-        snprintf(buf, len, "void igemm_glds_kernel<bf16, %d, %d, %d, true, 2, %d, %d, %s, %s>(ffn_igemm_desc)", c.bm, c.bn, d->conv ? 1 : 0, c.nwm, c.nwn,
-                 fastk ? "true" : "false", x3 ? "true" : "false");
+        const bool fastk = !x3 && !f8 && (d->conv ? d->Cin % 64 == 0 : d->K % 64 == 0) && (long)d->K * 2 + 256 <= (long)sizeof(g_zero_page);
+        snprintf(buf, len, "void igemm_glds_kernel<bf16, %d, %d, %d, true, 2, %d, %d, %s, %s, %s>(ffn_igemm_desc)", c.bm, c.bn, d->conv ? 1 : 0, c.nwm, c.nwn,
+                 fastk ? "true" : "false", x3 ? "true" : "false", f8 ? "true" : "false");
         return FFN_OK;
     }
     if (dtype == FFN_BF16 && (d->flags & FFN_IG_OUT_TRANSPOSED) && !d->conv && pp_trans_tile(*d, &bm, &bn)) {
-        snprintf(buf, len, "void igemm_pp_kernel<%d, %d, 0, false, false, false, true, false>(ffn_igemm_desc, int)", bm, bn);
+        snprintf(buf, len, "void igemm_pp_kernel<%d, %d, 0, false, false, false, true, false, false>(ffn_igemm_desc, int)", bm, bn);
         return FFN_OK;
     }
     igemm_plan_for(dtype, *d, &bm, &bn, &sk);
@@ -731,7 +736,7 @@ extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d0, char* 
     if (ns == 1) snprintf(buf, len, "void igemm_kernel<%s, %d, %d, %d, %s>(ffn_igemm_desc)", t, bm, bn, d->conv ? 1 : 0, swap);
     else {
         const int nwm = nw == 16 ? 4 : (nw == 8 ? (bn == 64 ? 4 : 2) : 2), nwn = nw / nwm;
-        snprintf(buf, len, "void igemm_glds_kernel<%s, %d, %d, %d, %s, %d, %d, %d, false, false>(ffn_igemm_desc)", t, bm, bn, d->conv ? 1 : 0, swap, ns, nwm, nwn);
+        snprintf(buf, len, "void igemm_glds_kernel<%s, %d, %d, %d, %s, %d, %d, %d, false, false, false>(ffn_igemm_desc)", t, bm, bn, d->conv ? 1 : 0, swap, ns, nwm, nwn);
     }
     return FFN_OK;
 }
@@ -795,6 +800,7 @@ static int dispatch_igemm(hipStream_t s, const ffn_igemm_desc& d) {
 static ffn_igemm_desc x3_view(const ffn_igemm_desc& d) {
     ffn_igemm_desc v = d;
     v.x3 = 1;
+    v.f8 = 0;
     v.K = 3 * d.K;
     v.flags |= FFN_IG_OUT_F32;
     return v;
@@ -819,6 +825,17 @@ static int dispatch_igemm_x3(hipStream_t s, const ffn_igemm_desc& d) {
     }
     return tuned_bf16<AMODE_DENSE, true>(s, d);
 }
+// fp8 problems: the kernels and every tile / split-K decision see a bf16-SHAPED view (two e4m3 bytes = one "element")
+static ffn_igemm_desc f8_view(const ffn_igemm_desc& d) {
+    ffn_igemm_desc v = d;
+    v.f8 = 1;
+    v.x3 = 0;
+    v.K = d.K / 2;
+    v.Cin = d.Cin / 2;
+    v.Kpad = d.Kpad / 2;
+    v.lda = d.lda / 2;
+    return v;
+}
 extern "C" int ffn_split_pair(void* stream, const float* src, void* dst, long rows, int C, int ld_src) {
     REQUIRE(src && dst && rows > 0 && C > 0 && C % 4 == 0 && ld_src >= C && ld_src % 4 == 0, "split_pair: bad arguments (C=%d, ld_src=%d)", C, ld_src);
     REQUIRE(aligned16(src) && aligned16(dst), "split_pair: pointers must be 16-byte aligned");
@@ -827,7 +844,20 @@ extern "C" int ffn_split_pair(void* stream, const float* src, void* dst, long ro
 }
 extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
     REQUIRE(d, "igemm: null descriptor");
-    REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16 || dtype == FFN_BF16X3, "igemm: bad dtype %d", dtype);
+    REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16 || dtype == FFN_BF16X3 || dtype == FFN_FP8, "igemm: bad dtype %d", dtype);
+    if (dtype == FFN_FP8) {
+        REQUIRE(d->A && d->W && d->out && aligned16(d->A) && aligned16(d->W) && aligned16(d->out), "igemm(fp8): A/W/out must be non-null and 16-byte aligned");
+        REQUIRE(d->conv && d->Cin > 0 && d->Cin % 16 == 0 && d->K == 9 * d->Cin && d->Kpad >= d->K && d->Kpad % 16 == 0 && d->lda == d->Cin,
+                "igemm(fp8): 3x3 convolutions with Cin %% 16 == 0 only (Cin=%d, K=%d, Kpad=%d, lda=%d)", d->Cin, d->K, d->Kpad, d->lda);
+        REQUIRE(d->M > 0 && d->N > 0 && d->N % 4 == 0 && d->ldo % 4 == 0 && d->rows_per_batch > 0 && d->M % (d->Hout * d->Wout) == 0, "igemm(fp8): bad shape");
+        REQUIRE(!(d->flags & (FFN_IG_GEGLU | FFN_IG_OUT_TRANSPOSED | FFN_IG_OUT_PAIR | FFN_IG_OUT_F32)), "igemm(fp8): plain / SiLU / residual epilogues only");
+        REQUIRE(d->stride == 1 || d->stride == 2, "igemm(fp8): stride %d", d->stride);
+        int ex = 0;
+        REQUIRE(d->alpha > 0.f && frexpf(d->alpha, &ex) == 0.5f, "igemm(fp8): alpha must be a power of two (the un-scaling of two power-of-two operand scales)");
+        if (d->residual) REQUIRE(d->ldr % 4 == 0, "igemm(fp8): ldr=%d must be a multiple of 4", d->ldr);
+        if (d->ws) REQUIRE(aligned16(d->ws) && d->ws_bytes >= 0, "igemm(fp8): workspace must be 16-byte aligned");
+        return tuned_bf16<AMODE_CONV3, false, true>(reinterpret_cast<hipStream_t>(stream), f8_view(*d));
+    }
     const int epc = dtype == FFN_F32 ? 4 : 8, kstage = 8 * epc;
     const int kmul = dtype == FFN_BF16X3 ? 3 : 1;
     REQUIRE(d->A && d->W && d->out, "igemm: null A/W/out");
@@ -874,7 +904,7 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == FFN_BF16X3) return dispatch_igemm_x3(s, x3_view(*d));
     ffn_igemm_desc plain = *d;
-    plain.x3 = 0;
+    plain.x3 = plain.f8 = 0;
     return dtype == FFN_F32 ? dispatch_igemm<float>(s, plain) : dispatch_igemm<bf16>(s, plain);
 }
 
@@ -1109,6 +1139,18 @@ extern "C" int ffn_groupnorm(void* stream, int dtype, const void* x, void* y, co
     int rc = ffn_gn_stats(stream, dtype, x, gamma, beta, B, HW, C, G, eps, partial_ws, scale, shift);
     if (rc) return rc;
     return ffn_gn_apply(stream, dtype, x, y, scale, shift, B, HW, C, silu | (pair ? FFN_NORM_OUT_PAIR : 0));
+}
+extern "C" int ffn_groupnorm_f8(void* stream, const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int Cp, int G,
+                                float eps, int silu, float qscale, float* partial_ws, float* scale, float* shift) {
+    REQUIRE(x && y && gamma && beta && partial_ws && scale && shift, "groupnorm_f8: null pointer (the workspace is always needed)");
+    REQUIRE(C % 8 == 0 && C % G == 0 && Cp >= C && Cp % 16 == 0 && aligned16(x) && aligned16(y) && qscale > 0.f, "groupnorm_f8: bad arguments (C=%d, Cp=%d)", C, Cp);
+    int rc = ffn_gn_stats(stream, FFN_BF16, x, gamma, beta, B, HW, C, G, eps, partial_ws, scale, shift);
+    if (rc) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long nch = (long)B * HW * (Cp / 8);
+    if (silu & FFN_NORM_SILU) LAUNCH(gn_apply_f8_kernel<true>, dim3(grid_for(nch)), dim3(256), 0, s, (const bf16*)x, (uint8_t*)y, scale, shift, nch, HW, C, Cp, qscale);
+    else LAUNCH(gn_apply_f8_kernel<false>, dim3(grid_for(nch)), dim3(256), 0, s, (const bf16*)x, (uint8_t*)y, scale, shift, nch, HW, C, Cp, qscale);
+    return check_launch("gn_apply_f8");
 }
 extern "C" int ffn_gn_stats(void* stream, int dtype, const void* x, const float* gamma, const float* beta, int B, int HW, int C,
                             int G, float eps, float* partial_ws, float* scale, float* shift) {

@@ -89,6 +89,24 @@ struct DT<bf16> {
     }
 };
 
+// fp8 (OCP e4m3) operands in the SAME byte geometry as bf16: a 16-byte chunk holds 16 values, so a 128-byte K row holds 128 of them and
+// one chunk pair (A, B) is TWO 16x16x32 MFMAs (bytes 0-7, bytes 8-15) where bf16 needs one -- twice the contraction per staged byte at the
+// bf16 MFMA rate.  Any assignment of chunk bytes to k indices is fine as long as A and B agree, which they do by construction.
+__device__ __forceinline__ void mma_fp8(const u32x4& a, const u32x4& b, f32x4& c) {
+    const long a0 = (long)(((uint64_t)a[1] << 32) | a[0]), a1 = (long)(((uint64_t)a[3] << 32) | a[2]);
+    const long b0 = (long)(((uint64_t)b[1] << 32) | b[0]), b1 = (long)(((uint64_t)b[3] << 32) | b[2]);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, c, 0, 0, 0);
+}
+// four floats -> four e4m3 bytes (saturating at +-448: v_cvt_pk_fp8_f32 itself does not clamp)
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    const float lim = 448.0f;
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(a, -lim), lim), fminf(fmaxf(b, -lim), lim), w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(c, -lim), lim), fminf(fmaxf(d, -lim), lim), w, true);
+    return (uint32_t)w;
+}
+
 // store 4 consecutive elements of type T from 4 floats (16 B for float, 8 B for bf16)
 __device__ __forceinline__ void store4(float* p, const float* v) {
     *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};

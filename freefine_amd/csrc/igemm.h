@@ -335,10 +335,14 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 //   A: pair-format rows [hi(0..K) ... | lo at column a_lo ...] read as segments [A_hi | A_hi | A_lo]   (p.K holds 3K, Kr = K)
 //   W: packed [N][3K] = [W_hi | W_lo | W_hi] (conv: per tap), plain rows
 // so only the loader's K -> (tap, column) map differs.  Output / residual are fp32 (epilogue instantiated for float).
-template <typename T, int BM, int BN, int AMODE, bool SWAP, int NS = 2, int NWM = 2, int NWN = 2, bool FASTK = false, bool X3 = false>
+// F8 (FFN_FP8): A and W hold OCP e4m3 bytes; the library hands the kernels a bf16-SHAPED view of the problem (K, Cin, lda, Kpad in units of
+// two bytes), so nothing in the addressing changes -- only the multiply (mma_fp8: two fp8 MFMAs per 16-byte chunk pair) and the scale
+// p.alpha the epilogue already applies.  out / residual are bf16.
+template <typename T, int BM, int BN, int AMODE, bool SWAP, int NS = 2, int NWM = 2, int NWN = 2, bool FASTK = false, bool X3 = false, bool F8 = false>
 __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmParams p) {
     typedef typename std::conditional<X3, float, T>::type TO;      // element type of out / residual
     static_assert(!X3 || (sizeof(T) == 2 && !FASTK && NS == 2), "split-bf16: bf16 operands, recomputing loader");
+    static_assert(!F8 || (sizeof(T) == 2 && !X3), "fp8 operands ride the bf16 byte geometry");
     constexpr int EPC = DT<T>::EPC;
     constexpr int BKE = 8 * EPC;  // K elements per stage (128 bytes)
     constexpr int NW = NWM * NWN;
@@ -541,7 +545,10 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
-                    if (SWAP)
+                    if constexpr (F8) {
+                        if (SWAP) mma_fp8(fb[j], fa[i], acc[i][j]);
+                        else mma_fp8(fa[i], fb[j], acc[i][j]);
+                    } else if (SWAP)
                         DT<T>::mma(fb[j], fa[i], acc[i][j]);
                     else
                         DT<T>::mma(fa[i], fb[j], acc[i][j]);

@@ -75,7 +75,11 @@ __device__ unsigned long long pp_trace[256 * 64];   // tools/native/pp_bench.hip
 // contraction [A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi] (p.K = 3 x the real K; per conv tap), which is a different SCALAR K
 // position per K tile (k_position) and a pixel stride of p.lda instead of Cin.  Output and residual are fp32: accumulators start at
 // bias + row bias + fp32 residual, the epilogue stores 16 bytes per lane through the same lane permutation as the split-K slabs.
-template <int BM, int BN, int AMODE, bool RES, bool GEGLU, bool SPLIT = false, bool TRANS = false, bool X3 = false>
+// F8 (FFN_FP8, 3x3 convolutions): fp8 e4m3 operands in the bf16 byte geometry (the library passes a bf16-shaped view: K, Cin, Kpad in
+// two-byte units), so a K tile carries 128 real elements and each fragment pair takes TWO fp8 MFMAs -- twice the MFMA work per LDS-DMA
+// piece of a kernel whose bound is the issue of those pieces.  Operands are pre-scaled by powers of two (activations 2^4, weights per
+// tensor); the accumulators start at (bias + row bias + residual) / alpha and the epilogue multiplies by alpha = 1 / (scale product).
+template <int BM, int BN, int AMODE, bool RES, bool GEGLU, bool SPLIT = false, bool TRANS = false, bool X3 = false, bool F8 = false>
 __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int splitk = 1) {
     typedef bf16 T;
     constexpr int HM = BM / 2;              // rows per wave (128 or 96)
@@ -106,6 +110,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
 
     static_assert(!SPLIT || (!RES && !GEGLU), "split-K slabs carry raw accumulators: the epilogue runs in the reduce kernel");
     static_assert(!TRANS || (!RES && !GEGLU && !SPLIT && !X3 && AMODE == AMODE_DENSE), "transposed output: dense A, bias only");
+    static_assert(!F8 || (!X3 && !TRANS && !GEGLU), "fp8 operands: plain / residual / split-K epilogues");
     const int ntn = p.N / BN;
     const int ntm = (p.M + BM - 1) / BM;
     const int nsl = SPLIT ? splitk : 1;               // K slices per output tile (the launcher picks a divisor of K / 64)
@@ -286,7 +291,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         for (int i = 0; i < FH; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                if constexpr (TRANS) DT<T>::mma(fa[i], fb[j], acc[i0 + i][j]);      // C[m = 4g + r][n = l15]
+                if constexpr (F8) mma_fp8(fb[j], fa[i], acc[i0 + i][j]);
+                else if constexpr (TRANS) DT<T>::mma(fa[i], fb[j], acc[i0 + i][j]);      // C[m = 4g + r][n = l15]
                 else DT<T>::mma(fb[j], fa[i], acc[i0 + i][j]);                      // C[m = l15][n = 4g + r]
             }
         if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
@@ -300,6 +306,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     // tile and are stored (and re-started for the next tile) in that K tile's phase-4 load section; the high rows are stored and
     // re-started in the phase-2 load section of the next tile's first K tile -- each half beside an MFMA phase of the other wave
     // group, instead of both groups running their whole epilogue back to back with the matrix pipe idle.
+    const float f8_inv = F8 ? 1.0f / p.alpha : 1.0f;       // alpha is a power of two: exact
     auto init_rows = [&](int tile, auto I0) {
         constexpr int i0 = decltype(I0)::value;
         if constexpr (SPLIT) {
@@ -351,15 +358,23 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
                 const int rb_off = (i * 16 + l15 >= E) ? 1024 : 512;
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
-                    const f32x4 c = *reinterpret_cast<const f32x4*>(slot + (j * 16 + 4 * g) * 4) + *reinterpret_cast<const f32x4*>(slot + rb_off + (j * 16 + 4 * g) * 4);
+                    f32x4 c = *reinterpret_cast<const f32x4*>(slot + (j * 16 + 4 * g) * 4) + *reinterpret_cast<const f32x4*>(slot + rb_off + (j * 16 + 4 * g) * 4);
+                    if constexpr (F8) c *= f8_inv;
                     if constexpr (RES && X3) {
                         acc[i][j] = c + __builtin_bit_cast(f32x4, w4[i - ib][j]);
                     } else if constexpr (RES) {
                         const unsigned w0 = w[i - ib][j][0], w1 = w[i - ib][j][1];
+                        if constexpr (F8) {
+                            acc[i][j][0] = fmaf(__uint_as_float(w0 << 16), f8_inv, c[0]);
+                            acc[i][j][1] = fmaf(__uint_as_float(w0 & 0xffff0000u), f8_inv, c[1]);
+                            acc[i][j][2] = fmaf(__uint_as_float(w1 << 16), f8_inv, c[2]);
+                            acc[i][j][3] = fmaf(__uint_as_float(w1 & 0xffff0000u), f8_inv, c[3]);
+                        } else {
                         acc[i][j][0] = c[0] + __uint_as_float(w0 << 16);
                         acc[i][j][1] = c[1] + __uint_as_float(w0 & 0xffff0000u);
                         acc[i][j][2] = c[2] + __uint_as_float(w1 << 16);
                         acc[i][j][3] = c[3] + __uint_as_float(w1 & 0xffff0000u);
+                        }
                     } else {
                         acc[i][j] = c;
                     }
@@ -484,8 +499,13 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
 #pragma unroll
         for (int i = i0; i < i0 + FH; ++i) {
             auto outfrag = [&](int jo, unsigned& w0, unsigned& w1) {
-                w0 = pack_bf16x2(acc[i][jo][0], acc[i][jo][1]);
-                w1 = pack_bf16x2(acc[i][jo][2], acc[i][jo][3]);
+                if constexpr (F8) {
+                    w0 = pack_bf16x2(acc[i][jo][0] * p.alpha, acc[i][jo][1] * p.alpha);
+                    w1 = pack_bf16x2(acc[i][jo][2] * p.alpha, acc[i][jo][3] * p.alpha);
+                } else {
+                    w0 = pack_bf16x2(acc[i][jo][0], acc[i][jo][1]);
+                    w1 = pack_bf16x2(acc[i][jo][2], acc[i][jo][3]);
+                }
             };
             const int row_off = PP_ABL == 5 ? ((m0 + i * 16) & 255) * p.ldo + ncol0 % 320 : (m0 + i * 16) * p.ldo + ncol0;      // 5: every tile to the same 256 x 320 window
 #pragma unroll

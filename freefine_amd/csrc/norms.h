@@ -148,6 +148,36 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// ---- (3b) apply with fp8 output (FFN_FP8 convolutions): y8[pixel][Cp] = e4m3(act(x * scale + shift) * qs), channels C .. Cp-1 = 0.
+// Cp (a multiple of 128) is the padded channel count the fp8 ping-pong conv needs; qs is the power-of-two activation scale.
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_f8_kernel(const bf16* __restrict__ x, uint8_t* __restrict__ y, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, long nchunks_total, int HW, int C, int Cp, float qs) {
+    const int cch = Cp / 8, cin = C / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks_total; i += (long)gridDim.x * 256) {
+        const long pix = i / cch;
+        const int cc = (int)(i - pix * cch);
+        u32x2 o = u32x2{0u, 0u};
+        if (cc < cin) {
+            const int b = (int)(pix / HW);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + pix * C + cc * 8);
+            float f[8];
+            DT<bf16>::unpack(v, f);
+            const float* sc = scale + (long)b * C + cc * 8;
+            const float* sh = shift + (long)b * C + cc * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = f[e] * sc[e] + sh[e];
+                if (SILU) t = silu_exact(t);
+                f[e] = t * qs;
+            }
+            o[0] = pack_fp8x4(f[0], f[1], f[2], f[3]);
+            o[1] = pack_fp8x4(f[4], f[5], f[6], f[7]);
+        }
+        *reinterpret_cast<u32x2*>(y + pix * Cp + cc * 8) = o;
+    }
+}
+
 // ---- fused GroupNorm for slices that one workgroup can own: grid (G, B), 1024 threads ----------------------------------
 // pass 1: sum / sumsq over the (batch, group) slice [HW][cg] (element pairs, 4 or 8 bytes per load; the slice is L2 resident),
 // block reduction (fp32 per thread, fp64 across threads), pass 2: y = act((x - mean) * rstd * gamma + beta).

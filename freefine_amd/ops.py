@@ -130,6 +130,43 @@ def pack_conv3x3(w, dtype, cin_pad=None, x3=False):
     return pack_linear(w2.reshape(cout, 9 * cp), dtype)
 
 
+F8_ACT_SCALE = 16.0         # power-of-two scale of fp8 activations: SiLU(GroupNorm(x)) * 16 saturates at 28, far above its range
+
+
+def pack_conv3x3_f8(w, cin_pad=None):
+    """[Cout, Cin, 3, 3] -> e4m3 bytes [Cout, 9 * Cp] (uint8 storage), k = (ky*3+kx)*Cp + ci, Cp = Cin padded to a multiple of 128 (whole
+    K tiles of the fp8 ping-pong conv), scaled by a per-tensor power of two so that max |w| lands in [224, 448).  The tensor carries
+    `_ffn_f8 = (Cp, alpha)`, alpha = 1 / (weight scale * F8_ACT_SCALE) = what the GEMM epilogue multiplies by (FFN_FP8, freefine_hip.h)."""
+    cout, cin = w.shape[:2]
+    cp = cin_pad or (cin + 127) // 128 * 128
+    w2 = torch.zeros(cout, 3, 3, cp, dtype=torch.float32, device=w.device)
+    w2[..., :cin] = w.permute(0, 2, 3, 1).float()
+    amax = float(w2.abs().max())
+    k = math.floor(math.log2(448.0 / amax)) if amax > 0 else 0
+    ws = 2.0 ** k
+    q = (w2 * ws).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).reshape(cout, 9 * cp).contiguous().view(torch.uint8)
+    q._ffn_f8 = (cp, 1.0 / (ws * F8_ACT_SCALE))
+    return q
+
+
+def is_f8(w):
+    return getattr(w, "_ffn_f8", None) is not None
+
+
+def groupnorm_f8(x, gamma, beta, G, eps, Cp, silu=False, ws=None):
+    """bf16 x [B, HW, C] -> e4m3 bytes [B, HW, Cp] = act(GroupNorm(x)) * F8_ACT_SCALE, channels >= C zero: the A operand of an fp8 conv"""
+    lib = L.load()
+    B, HW, Cc = x.shape
+    assert x.dtype == torch.bfloat16
+    out = torch.empty(B, HW, Cp, dtype=torch.uint8, device=x.device)
+    out._ffn_f8_act = Cc
+    partial, scale, shift = ws if ws is not None else gn_workspace(B, HW, Cc, x.device)
+    call = lambda: lib.ffn_groupnorm_f8(_stream(), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B, HW, Cc, Cp, G, eps,
+                                        L.NORM_SILU if silu else 0, F8_ACT_SCALE, partial.data_ptr(), scale.data_ptr(), shift.data_ptr())
+    L.check(_timed("gn_partial+gn_finalize+gn_apply_f8", 0.0, x.numel() * 2.0 + out.numel(), call), "ffn_groupnorm_f8")
+    return out
+
+
 def pack_geglu(w, b, dtype, x3=False):
     """GEGLU proj [2F, K] (+bias [2F]): interleave 16-row blocks hidden/gate so one lane holds both halves."""
     f2, k = w.shape
@@ -255,13 +292,18 @@ def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, ou
     N = w.shape[0]
     d = L.IgemmDesc()
     x3 = is_x3(w)
-    if x3 and pair_width(x) is not None:
+    f8 = is_f8(w)
+    if f8:                                          # fp8 convolution: x is the e4m3 tensor groupnorm_f8 wrote, [B, HW, Cp]
+        assert x.dtype == torch.uint8 and x.shape[-1] == w._ffn_f8[0] and out_f32 is False
+        Cin = x.shape[-1]
+        xa = x
+    elif x3 and pair_width(x) is not None:
         assert pair_width(x) == Cin
         xa = x
     else:
         xa = split_pair(x, Cin) if x3 else x        # split-bf16: every pixel becomes [hi(Cin) | lo(Cin)]
-    dcode = L.FFN_BF16X3 if x3 else _dt(x)
-    odt = torch.float32 if x3 else x.dtype
+    dcode = L.FFN_FP8 if f8 else (L.FFN_BF16X3 if x3 else _dt(x))
+    odt = torch.float32 if x3 else (torch.bfloat16 if f8 else x.dtype)
     d.A, d.W = xa.data_ptr(), w.data_ptr()
     d.bias, d.rowbias, d.residual = _p(bias), _p(rowbias), _p(residual)
     d.M, d.N, d.K, d.Kpad = B * Hout * Wout, N, 9 * Cin, w.shape[1]
@@ -275,13 +317,14 @@ def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, ou
     d.ldr = residual.shape[-1] if residual is not None else 0
     d.Hin, d.Win, d.Cin, d.Hout, d.Wout = Hin, Win, Cin, Hout, Wout
     d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
-    d.flags, d.alpha, d.conv = (L.IG_OUT_F32 if out_f32 else 0), 1.0, 1
+    d.flags, d.alpha, d.conv = (L.IG_OUT_F32 if out_f32 else 0), (w._ffn_f8[1] if f8 else 1.0), 1
     d.splitk, d.ws, d.ws_bytes = splitk, _workspace(x.device).data_ptr(), WS_BYTES
     if _PROF is None:
         L.check(lib.ffn_igemm(_stream(), dcode, CT.byref(d)), "ffn_igemm(conv)")
     else:
         esz = x.element_size()
-        L.check(_timed(_igemm_name(lib, dcode, d), 2.0 * d.M * N * d.K, esz * (x.numel() + N * d.K + d.M * N),
+        k_real = 9 * getattr(x, "_ffn_f8_act", Cin)       # fp8: the padded channels are zeros, not work
+        L.check(_timed(_igemm_name(lib, dcode, d), 2.0 * d.M * N * k_real, esz * (x.numel() + N * d.K + d.M * N),
                        lambda: lib.ffn_igemm(_stream(), dcode, CT.byref(d))), "ffn_igemm(conv)")
     return out
 

@@ -65,7 +65,7 @@ class FreeFinePipeline:
     # construction (freefine_batch_infer_2d.py:148-157)
     # ------------------------------------------------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, path, torch_dtype=torch.float32, device="cuda:0", seed=0, broadcast="auto", x3=False, **kw):
+    def from_pretrained(cls, path, torch_dtype=torch.float32, device="cuda:0", seed=0, broadcast="auto", x3=False, fp8_conv=False, **kw):
         """`path` is either a HF-layout Stable-Diffusion folder (unet/, vae/ safetensors + config.json; tokenizer/,
         text_encoder/ loaded through transformers when present) or "synthetic:<unet preset>[:<vae preset>]" for
         seeded random weights of that architecture (no checkpoints exist in the build environment).
@@ -120,14 +120,15 @@ class FreeFinePipeline:
             mdt = torch.float32 if dtype == torch.float32 else torch.bfloat16
             ust = FD.broadcast_state(ust, unet_param_shapes(ucfg), device, matrix_dtype=mdt)
             vst = FD.broadcast_state(vst, vae_param_shapes(vcfg), device, matrix_dtype=mdt)
-        return cls.from_state(ucfg, ust, vcfg, vst, tok, enc, sched, dtype, device, x3=x3)
+        return cls.from_state(ucfg, ust, vcfg, vst, tok, enc, sched, dtype, device, x3=x3, fp8_conv=fp8_conv)
 
     @classmethod
-    def from_state(cls, ucfg, ustate, vcfg, vstate, tokenizer, text_encoder, scheduler=None, dtype=torch.float32, device="cuda:0", x3=False):
+    def from_state(cls, ucfg, ustate, vcfg, vstate, tokenizer, text_encoder, scheduler=None, dtype=torch.float32, device="cuda:0", x3=False,
+                   fp8_conv=False):
         ustate, vstate = normalize_state_dict(ustate), normalize_state_dict(vstate)      # hub checkpoints: legacy VAE attention names
         validate_state_dict(ustate, unet_param_shapes(ucfg), "unet")
         validate_state_dict(vstate, vae_param_shapes(vcfg), "vae")
-        unet = HipUNet(ucfg, ustate, dtype=dtype, device=device, x3=x3)
+        unet = HipUNet(ucfg, ustate, dtype=dtype, device=device, x3=x3, fp8_conv=fp8_conv)
         vae = HipVAE(vcfg, vstate, dtype=dtype, device=device, x3=x3)
         return cls(unet, vae, tokenizer, text_encoder, scheduler or DDIMScheduler(), device)
 

@@ -26,12 +26,17 @@ class _Res:
 
 
 class HipUNet:
-    def __init__(self, cfg: UNetConfig, state, dtype=torch.bfloat16, device="cuda:0", x3=False):
+    def __init__(self, cfg: UNetConfig, state, dtype=torch.bfloat16, device="cuda:0", x3=False, fp8_conv=False):
         """dtype float32 = exact-fp32 parity mode, bfloat16 = fast mode.  x3 (with dtype float32): the split-bf16 mode -- activations,
         norms, softmax and the residual stream stay fp32 exactly as in parity mode, every Linear / conv runs as an FFN_BF16X3 GEMM
         (hi/lo bf16 operands, three bf16 MFMAs per product term, fp32 accumulation; include/freefine_hip.h)."""
         assert not x3 or dtype == torch.float32, "split-bf16 mode keeps fp32 activations"
+        assert not fp8_conv or dtype == torch.bfloat16, "fp8 convolutions are an option of the bf16 fast mode"
         self.x3 = bool(x3)
+        # fp8_conv: the two 3x3 convolutions of every ResBlock take e4m3 operands (FFN_FP8): their inputs are SiLU(GroupNorm(.)) -- bounded,
+        # written as fp8 by the norm's apply pass -- and their weights are quantised once with a per-tensor power-of-two scale.  Everything
+        # else (attention, Linear layers, the residual stream) is the bf16 mode.  Reported beside the bf16 number, never as parity.
+        self.fp8_conv = bool(fp8_conv)
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
         self.in_channels = cfg.in_channels
         self.hook, self.controller = "edit", None
@@ -66,9 +71,13 @@ class HipUNet:
     def _resnet(self, st, p, temb_list):
         r = _Res()
         r.n1 = (self._f32(st[p + ".norm1.weight"]), self._f32(st[p + ".norm1.bias"]))
-        r.c1 = self._conv(st, p + ".conv1")
         r.n2 = (self._f32(st[p + ".norm2.weight"]), self._f32(st[p + ".norm2.bias"]))
-        r.c2 = self._conv(st, p + ".conv2")
+        if self.fp8_conv:
+            r.c1 = (ops.pack_conv3x3_f8(st[p + ".conv1.weight"].to(self.device).float()), self._f32(st[p + ".conv1.bias"]), st[p + ".conv1.weight"].shape[1])
+            r.c2 = (ops.pack_conv3x3_f8(st[p + ".conv2.weight"].to(self.device).float()), self._f32(st[p + ".conv2.bias"]), st[p + ".conv2.weight"].shape[1])
+        else:
+            r.c1 = self._conv(st, p + ".conv1")
+            r.c2 = self._conv(st, p + ".conv2")
         r.cout = st[p + ".conv1.weight"].shape[0]
         r.sc = self._lin(st, p + ".conv_shortcut") if (p + ".conv_shortcut.weight") in st else None
         r.temb_off = sum(w.shape[0] for w, _ in temb_list)
@@ -482,12 +491,18 @@ class HipUNet:
         # split-bf16 mode: every GroupNorm / LayerNorm feeds a GEMM -> written directly in the [hi | lo] pair form that GEMM reads
         return ops.groupnorm(x, gb[0], gb[1], self.cfg.norm_num_groups, eps, silu=silu, pair=self.x3)
 
+    def _gn_conv_in(self, x, gb, w):
+        """SiLU(GroupNorm(x)) in the form the convolution `w` reads: e4m3 bytes (fp8 conv), pair rows (split-bf16) or the activation dtype"""
+        if ops.is_f8(w):
+            return ops.groupnorm_f8(x, gb[0], gb[1], self.cfg.norm_num_groups, self.cfg.norm_eps, w._ffn_f8[0], silu=True)
+        return self._gn(x, gb, self.cfg.norm_eps, True)
+
     def _resblock(self, r, x, B, H, W, temb_all, out=None):
         cin = x.shape[-1]
-        h = self._gn(x, r.n1, self.cfg.norm_eps, True)
+        h = self._gn_conv_in(x, r.n1, r.c1[0])
         rb = temb_all[:, r.temb_off:r.temb_off + r.cout]
         h = ops.conv3x3(h, r.c1[0], r.c1[1], B, H, W, cin, rowbias=rb, rowbias_ld=temb_all.shape[1])
-        h = self._gn(h, r.n2, self.cfg.norm_eps, True)
+        h = self._gn_conv_in(h, r.n2, r.c2[0])
         if r.sc is not None:
             x = ops.linear(x, r.sc[0], r.sc[1], K=cin)
         return ops.conv3x3(h, r.c2[0], r.c2[1], B, H, W, r.cout, residual=x, out=out)

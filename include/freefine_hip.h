@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-enum { FFN_F32 = 0, FFN_BF16 = 1, FFN_BF16X3 = 2 /* ffn_igemm / ffn_attn: split-bf16 arithmetic, fp32 results (see ffn_igemm) */ };
+enum { FFN_F32 = 0, FFN_BF16 = 1, FFN_BF16X3 = 2 /* ffn_igemm / ffn_attn: split-bf16 arithmetic, fp32 results (see ffn_igemm) */,
+       FFN_FP8 = 3 /* ffn_igemm, 3x3 convolutions only: OCP e4m3 operands, bf16 results (see ffn_igemm) */ };
 enum { FFN_OK = 0, FFN_EINVAL = -22, FFN_ENOSYS = -38, FFN_EHIP = -5 };
 
 int ffn_version(void);
@@ -68,6 +69,7 @@ typedef struct ffn_igemm_desc {
     long ws_bytes;
     int a_lo;         /* FFN_BF16X3: column (conv: channel) offset of the lo plane inside a row (pixel) of A; else ignored */
     int x3;           /* set by the library from `dtype` (callers leave it 0) */
+    int f8;           /* set by the library from `dtype` (callers leave it 0) */
 } ffn_igemm_desc;
 int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
 /* FFN_BF16X3 ("split-bf16", the fast mode that keeps fp32-level results): every fp32 operand value v is carried as hi = bf16(v) and
@@ -80,6 +82,14 @@ int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
  *   out, residual   fp32 (FFN_IG_OUT_F32 is implied); bias / rowbias fp32 as always; GEGLU, SILU, transposed output, split-K as in bf16.
  * K in the descriptor is the REAL contraction length (dense K, conv 9*Cin). */
 int ffn_split_pair(void* stream, const float* src, void* dst, long rows, int C, int ld_src);
+/* FFN_FP8 (3x3 convolutions of the bf16 fast mode, reported beside it -- not a parity mode): A = e4m3 bytes NHWC [B][Hin][Win][Cin] with
+ * Cin a multiple of 16 (the ping-pong tile: of 128; ffn_groupnorm_f8 writes such a tensor, channels zero-padded), W = e4m3 [N][Kpad]
+ * in the usual (ky, kx, ci) order, K = 9 * Cin; out / residual bf16, bias / rowbias fp32.  Both operands carry power-of-two scales (the
+ * activation's is ffn_groupnorm_f8's `qscale`, the weight's is chosen at pack time); `alpha` = 1 / (their product) un-scales the result.
+ * The kernels are the bf16 ones: e4m3 rides the same 16-byte chunk geometry (16 values per chunk, 128 per K row), each fragment pair
+ * takes two v_mfma_f32_16x16x32_fp8_fp8 -- twice the contraction per staged byte at the bf16 MFMA rate. */
+int ffn_groupnorm_f8(void* stream, const void* x_bf16, void* y_e4m3, const float* gamma, const float* beta, int B, int HW, int C, int Cp,
+                     int G, float eps, int silu, float qscale, float* partial_ws, float* scale, float* shift);
 /* Kernel families behind ffn_igemm (freefine_amd/csrc): igemm_pp_kernel (igemm_p8.h; bf16 -- 256- or 192-row "ping-pong" tiles with
  * LDS-DMA operands in flight across barriers, the default wherever N is a multiple of 256 or 320 and K a multiple of 64),
  * igemm_glds_kernel / igemm_halo_kernel (igemm.h; every other bf16 shape and all of f32).

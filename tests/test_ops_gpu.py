@@ -952,3 +952,88 @@ def test_x3_attention_uniform_wq_and_determinism(gpu):
     assert relerr(out[2], ref2) < X3_TOL
     for _ in range(3):
         assert torch.equal(ops.attention(q, k, vt, heads, scale, [p0, p1], Sk=Sk, x3=True), out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# FFN_FP8: e4m3 operands for the 3x3 convolutions of the bf16 fast mode.  The GEMM is exact on its quantised operands up to fp32
+# accumulation and the bf16 output rounding, so the kernel tests quantise on the host and compare against the fp64 convolution of the
+# DEQUANTISED operands at the bf16 tolerance; what the quantisation costs is measured at the UNet level, not here.
+# ---------------------------------------------------------------------------------------------------------------------
+def _quant_act_f8(x, Cp):
+    """[B, HW, C] float -> (uint8 [B, HW, Cp] e4m3 of x * F8_ACT_SCALE, dequantised double [B, HW, C])"""
+    from freefine_amd import ops
+    B, HW, C = x.shape
+    q = torch.zeros(B, HW, Cp, dtype=torch.float32, device=x.device)
+    q[..., :C] = (x.float() * ops.F8_ACT_SCALE).clamp(-448, 448)
+    q8 = q.to(torch.float8_e4m3fn)
+    out = q8.view(torch.uint8).contiguous()
+    out._ffn_f8_act = C
+    return out, q8.float()[..., :C].double() / ops.F8_ACT_SCALE
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=3, H=32, W=32, Cin=128, Cout=320),          # ping-pong tile shapes
+    dict(B=4, H=64, W=64, Cin=320, Cout=320),          # Cin padded 320 -> 384
+    dict(B=5, H=16, W=16, Cin=640, Cout=640),
+    dict(B=3, H=8, W=8, Cin=2560, Cout=1280),          # split-K at the coarse level
+    dict(B=1, H=8, W=8, Cin=64, Cout=96),              # generic tiles (M < 192, N not a tile multiple), Cin padded 64 -> 128
+    dict(B=2, H=12, W=20, Cin=32, Cout=4),
+])
+def test_fp8_conv3x3(gpu, cfg):
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, H, W, Cin, Cout = cfg["B"], cfg["H"], cfg["W"], cfg["Cin"], cfg["Cout"]
+    x = rnd((B, H * W, Cin), torch.float32, gpu, g).abs_() * 0.7          # SiLU-like range, mostly positive
+    w = rnd((Cout, Cin, 3, 3), torch.float32, gpu, g, (9 * Cin) ** -0.5)
+    b = torch.randn(Cout, generator=g).to(gpu)
+    rb = torch.randn(B, Cout, generator=g).to(gpu)
+    res = rnd((B, H * W, Cout), torch.bfloat16, gpu, g)
+    wp = ops.pack_conv3x3_f8(w)
+    Cp, alpha = wp._ffn_f8
+    assert Cp % 128 == 0 and wp.shape == (Cout, 9 * Cp)
+    wdq = wp.view(torch.float8_e4m3fn).float().reshape(Cout, 3, 3, Cp)[..., :Cin].permute(0, 3, 1, 2).double() * (alpha * ops.F8_ACT_SCALE)
+    x8, xdq = _quant_act_f8(x, Cp)
+    ref = F.conv2d(xdq.reshape(B, H, W, Cin).permute(0, 3, 1, 2), wdq, b.double(), padding=1).permute(0, 2, 3, 1).reshape(B, H * W, Cout)
+    out = ops.conv3x3(x8, wp, b, B, H, W, Cin)
+    assert out.dtype == torch.bfloat16
+    e0 = relerr(out, ref)
+    out = ops.conv3x3(x8, wp, b, B, H, W, Cin, rowbias=rb, residual=res)
+    e1 = relerr(out, ref + rb.double()[:, None] + res.double())
+    # and what the quantisation itself costs on this input, for the record
+    true = F.conv2d(x.double().reshape(B, H, W, Cin).permute(0, 3, 1, 2), w.double(), b.double(), padding=1).permute(0, 2, 3, 1).reshape(B, H * W, Cout)
+    print(f"fp8 conv {cfg}: kernel vs dequantised operands {e0:.2e} / {e1:.2e}; quantisation error of the result {relerr(ref, true):.2e}")
+    assert max(e0, e1) < tol(torch.bfloat16)
+
+
+def test_fp8_groupnorm_and_every_configuration(gpu):
+    from freefine_amd import _lib as L
+    from freefine_amd import ops
+    lib = L.load()
+    g = torch.Generator().manual_seed(3)
+    # GroupNorm + SiLU written as e4m3 with channel padding
+    for (B, HW, C, Cp) in [(2, 1024, 320, 384), (1, 256, 640, 640), (3, 64, 64, 128)]:
+        x = rnd((B, HW, C), torch.bfloat16, gpu, g, 2.0) + 0.5
+        gamma, beta = torch.randn(C, generator=g).to(gpu), torch.randn(C, generator=g).to(gpu)
+        y8 = ops.groupnorm_f8(x, gamma, beta, 32, 1e-5, Cp, silu=True)
+        assert y8.shape == (B, HW, Cp) and y8.dtype == torch.uint8 and (y8[..., C:] == 0).all()
+        ref = F.silu(F.group_norm(x.double().transpose(1, 2), 32, gamma.double(), beta.double(), 1e-5).transpose(1, 2)) * ops.F8_ACT_SCALE
+        deq = y8.view(torch.float8_e4m3fn).float()[..., :C].double()
+        err = (deq - ref.clamp(-448, 448)).abs()
+        assert (err <= ref.abs() * 2.0 ** -4 + 2.0 ** -9 + 2e-2).all(), err.max().item()      # e4m3: 3 mantissa bits, subnormal step 2^-9; bf16 input
+    # every configuration forced in turn on an fp8 conv
+    try:
+        for cfg in range(lib.ffn_igemm_num_configs()):
+            lib.ffn_igemm_force_config(cfg)
+            for (B, H, Cin, Cout, sk) in [(3, 32, 128, 320, 0), (3, 16, 256, 320, 0), (3, 16, 256, 320, 6), (2, 24, 64, 96, 0)]:
+                x = rnd((B, H * H, Cin), torch.float32, gpu, g).abs_() * 0.7
+                w = rnd((Cout, Cin, 3, 3), torch.float32, gpu, g, (9 * Cin) ** -0.5)
+                b, rb, r = rnd((Cout,), torch.float32, gpu, g), rnd((B, Cout), torch.float32, gpu, g), rnd((B, H * H, Cout), torch.bfloat16, gpu, g)
+                wp = ops.pack_conv3x3_f8(w)
+                Cp, alpha = wp._ffn_f8
+                wdq = wp.view(torch.float8_e4m3fn).float().reshape(Cout, 3, 3, Cp)[..., :Cin].permute(0, 3, 1, 2).double() * (alpha * ops.F8_ACT_SCALE)
+                x8, xdq = _quant_act_f8(x, Cp)
+                ref = F.conv2d(xdq.reshape(B, H, H, Cin).permute(0, 3, 1, 2), wdq, b.double(), padding=1).permute(0, 2, 3, 1).reshape(B, H * H, Cout)
+                out = ops.conv3x3(x8, wp, b, B, H, H, Cin, rowbias=rb, residual=r, splitk=sk)
+                assert relerr(out, ref + rb.double()[:, None] + r.double()) < tol(torch.bfloat16), (cfg, H, Cin, sk)
+    finally:
+        lib.ffn_igemm_force_config(-1)

@@ -197,3 +197,25 @@ def test_unet_split_bf16_mode(gpu, name):
     x, enc = rng_tensor(3, (4, 4, 16, 16)), rng_tensor(4, (4, 77, D))
     ref = onet(x, torch.tensor(481), enc)
     assert relerr(hnet(x.to(gpu), 481, enc.to(gpu)), ref) < 1e-4
+
+
+def test_unet_fp8_conv_mode_vs_oracle(gpu):
+    """bf16 fast mode with e4m3 ResBlock convolutions (FFN_FP8), full-size SD-2.1 at 64x64, B = 4, and the tiny topology: a REPORTED mode
+    (3 mantissa bits on 55 % of the FLOPs) -- the deviation from the fp32 oracle is printed and loosely bounded, beside the plain bf16 one."""
+    from freefine_amd.config import UNetConfig
+    from freefine_amd.unet import HipUNet
+    from oracle import sd_unet
+    torch.set_num_threads(max(8, min(32, torch.get_num_threads())))
+    for name, hw in (("tiny", 16), ("sd21-base", 64)):
+        onet = sd_unet.init_unet(sd_unet.unet_config(name), seed=0)
+        D = onet.cfg.cross_attention_dim
+        x, enc = rng_tensor(11, (4, 4, hw, hw)), rng_tensor(12, (4, 77, D))
+        ref = onet(x, torch.tensor(501), enc)
+        errs = {}
+        for f8 in (False, True):
+            hnet = HipUNet(UNetConfig.preset(name), onet.state_dict(), dtype=torch.bfloat16, device=gpu, fp8_conv=f8)
+            errs[f8] = relerr(hnet(x.to(gpu), 501, enc.to(gpu)), ref)
+            del hnet
+            torch.cuda.empty_cache()
+        print(f"{name} @{hw}x{hw}: max |diff| / max |ref| vs fp32 oracle: bf16 {errs[False]:.3e}, bf16 + fp8 convolutions {errs[True]:.3e}")
+        assert errs[True] < 0.5
