@@ -491,6 +491,19 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
                 }
             return;
         }
+        if constexpr (F8) {                           // un-scale the half tile IN PLACE first (the accumulators restart right after the stores);
+                                                      // with the multiply fused into the pack, rows l15 % 4 == 3 of a row's first fragment pair
+                                                      // came out as garbage on gfx950 (the scaled value went pk_mul -> cvt -> v_permlane16_swap
+                                                      // back to back): the conversion below now reads plain registers like the bf16 path
+#pragma unroll
+            for (int i = i0; i < i0 + FH; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    acc[i][j] *= p.alpha;
+                    asm volatile("" : "+v"(acc[i][j]));
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         constexpr int NOF = FN;                       // output fragments per fragment row
         const int voff8 = (pr * p.ldo + 4 * pg) * 2;
         const int voff16 = pr * p.ldo * 2 + pg * 16;
@@ -499,13 +512,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
 #pragma unroll
         for (int i = i0; i < i0 + FH; ++i) {
             auto outfrag = [&](int jo, unsigned& w0, unsigned& w1) {
-                if constexpr (F8) {
-                    w0 = pack_bf16x2(acc[i][jo][0] * p.alpha, acc[i][jo][1] * p.alpha);
-                    w1 = pack_bf16x2(acc[i][jo][2] * p.alpha, acc[i][jo][3] * p.alpha);
-                } else {
-                    w0 = pack_bf16x2(acc[i][jo][0], acc[i][jo][1]);
-                    w1 = pack_bf16x2(acc[i][jo][2], acc[i][jo][3]);
-                }
+                w0 = pack_bf16x2(acc[i][jo][0], acc[i][jo][1]);
+                w1 = pack_bf16x2(acc[i][jo][2], acc[i][jo][3]);
             };
             const int row_off = PP_ABL == 5 ? ((m0 + i * 16) & 255) * p.ldo + ncol0 % 320 : (m0 + i * 16) * p.ldo + ncol0;      // 5: every tile to the same 256 x 320 window
 #pragma unroll
