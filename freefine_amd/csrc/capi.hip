@@ -1143,11 +1143,11 @@ extern "C" int ffn_groupnorm(void* stream, int dtype, const void* x, void* y, co
 extern "C" int ffn_groupnorm_f8(void* stream, const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int Cp, int G,
                                 float eps, int silu, float qscale, float* partial_ws, float* scale, float* shift) {
     REQUIRE(x && y && gamma && beta && partial_ws && scale && shift, "groupnorm_f8: null pointer (the workspace is always needed)");
-    REQUIRE(C % 8 == 0 && C % G == 0 && Cp >= C && Cp % 16 == 0 && aligned16(x) && aligned16(y) && qscale > 0.f, "groupnorm_f8: bad arguments (C=%d, Cp=%d)", C, Cp);
+    REQUIRE(C % 16 == 0 && C % G == 0 && Cp >= C && Cp % 16 == 0 && aligned16(x) && aligned16(y) && qscale > 0.f, "groupnorm_f8: bad arguments (C=%d, Cp=%d)", C, Cp);
     int rc = ffn_gn_stats(stream, FFN_BF16, x, gamma, beta, B, HW, C, G, eps, partial_ws, scale, shift);
     if (rc) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const long nch = (long)B * HW * (Cp / 8);
+    const long nch = (long)B * HW * (Cp / 16);
     if (silu & FFN_NORM_SILU) LAUNCH(gn_apply_f8_kernel<true>, dim3(grid_for(nch)), dim3(256), 0, s, (const bf16*)x, (uint8_t*)y, scale, shift, nch, HW, C, Cp, qscale);
     else LAUNCH(gn_apply_f8_kernel<false>, dim3(grid_for(nch)), dim3(256), 0, s, (const bf16*)x, (uint8_t*)y, scale, shift, nch, HW, C, Cp, qscale);
     return check_launch("gn_apply_f8");

@@ -153,28 +153,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 template <bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_f8_kernel(const bf16* __restrict__ x, uint8_t* __restrict__ y, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, long nchunks_total, int HW, int C, int Cp, float qs) {
-    const int cch = Cp / 8, cin = C / 8;
+    // one thread = 16 channels of one pixel: two 16-byte loads, ONE 16-byte store (8-byte stores ran this pass at 2.5 TB/s of real traffic)
+    const int cch = Cp / 16;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks_total; i += (long)gridDim.x * 256) {
         const long pix = i / cch;
-        const int cc = (int)(i - pix * cch);
-        u32x2 o = u32x2{0u, 0u};
-        if (cc < cin) {
+        const int c0 = (int)(i - pix * cch) * 16;
+        u32x4 o = u32x4{0u, 0u, 0u, 0u};
+        if (c0 < C) {                                        // C % 16 == 0 is checked by the launcher
             const int b = (int)(pix / HW);
-            const u32x4 v = *reinterpret_cast<const u32x4*>(x + pix * C + cc * 8);
-            float f[8];
-            DT<bf16>::unpack(v, f);
-            const float* sc = scale + (long)b * C + cc * 8;
-            const float* sh = shift + (long)b * C + cc * 8;
+            const u32x4 v0 = *reinterpret_cast<const u32x4*>(x + pix * C + c0);
+            const u32x4 v1 = *reinterpret_cast<const u32x4*>(x + pix * C + c0 + 8);
+            float f[16];
+            DT<bf16>::unpack(v0, f);
+            DT<bf16>::unpack(v1, f + 8);
+            const float* sc = scale + (long)b * C + c0;
+            const float* sh = shift + (long)b * C + c0;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < 16; ++e) {
                 float t = f[e] * sc[e] + sh[e];
                 if (SILU) t = silu_exact(t);
                 f[e] = t * qs;
             }
-            o[0] = pack_fp8x4(f[0], f[1], f[2], f[3]);
-            o[1] = pack_fp8x4(f[4], f[5], f[6], f[7]);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) o[w] = pack_fp8x4(f[4 * w], f[4 * w + 1], f[4 * w + 2], f[4 * w + 3]);
         }
-        *reinterpret_cast<u32x2*>(y + pix * Cp + cc * 8) = o;
+        *reinterpret_cast<u32x4*>(y + pix * Cp + c0) = o;
     }
 }
 
