@@ -184,13 +184,20 @@ def parity_leg(args, device, model_fast):
             model_fast.FreeFine_generation(ori_img, ori_mask, coarse, tgt_mask, "a photo of a cup", 7.5, 1.0, **kw)
             ft = torch.stack([t.float() for t in model_fast.last_intermediates]).cpu()
             d = (ft - ref_traj).abs().flatten(1).max(dim=1).values
+            amax = ref_traj.abs().max().item()
+            out["latent_abs_max"] = round(amax, 3)
+            out["note"] = ("deviations are ABSOLUTE latent L-inf between two modes of this engine over the full schedule on seeded RANDOM weights, whose "
+                           "trajectory is not a denoising one (|latent| grows to latent_abs_max): divide by latent_abs_max for the relative figure; against "
+                           "the oracle on O(1) latents the gates are tests/test_pipeline_gpu.py (f32 <= 2e-5, bf16x3 <= 5e-4, tolerance 1e-3)")
             out[f"{args.dtype}_vs_{mode}_latent_linf"] = {"final": round(d[-1].item(), 5), "max_over_steps": round(d.max().item(), 5),
+                                                         "relative_to_latent_abs_max": float(f"{d.max().item() / amax:.3e}"),
                                                          "schedule": f"N={args.num_step}, start_step={args.start_step}, one image, seed 42",
-                                                         "latent_abs_max": round(ref_traj.abs().max().item(), 3)}
+                                                         "latent_abs_max": round(amax, 3)}
             dev = None
         else:
             d = (traj - ref_traj).abs().flatten(1).max(dim=1).values
-            dev = {"final": round(d[-1].item(), 6), "max_over_steps": round(d.max().item(), 6)}
+            dev = {"final": round(d[-1].item(), 6), "max_over_steps": round(d.max().item(), 6),
+                   "relative_to_latent_abs_max": float(f"{d.max().item() / ref_traj.abs().max().item():.3e}")}
         for i in range(2):                                   # warm-up (tuning, graph capture), then the timed step
             torch.cuda.synchronize()
             t0 = time.time()
@@ -227,7 +234,8 @@ def fp8_leg(args, device):
         m.FreeFine_generation(ori_img, ori_mask, coarse, tgt_mask, "a photo of a cup", 7.5, 1.0, end_step=args.num_step, num_step=args.num_step,
                               start_step=args.start_step, method_type="tca", verbose=False, seed=42, draw_mask=draw, end_scale=0.0, return_intermediates=True)
         d = (torch.stack([t.float() for t in m.last_intermediates]).cpu() - _F32_TRAJ).abs().flatten(1).max(dim=1).values
-        rec["latent_linf_vs_f32"] = {"final": round(d[-1].item(), 5), "max_over_steps": round(d.max().item(), 5)}
+        rec["latent_linf_vs_f32"] = {"final": round(d[-1].item(), 5), "max_over_steps": round(d.max().item(), 5),
+                                     "relative_to_latent_abs_max": float(f"{d.max().item() / _F32_TRAJ.abs().max().item():.3e}")}
     for i in range(2):
         torch.cuda.synchronize()
         t0 = time.time()
@@ -298,6 +306,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-ref-layout", dest="no_ref_layout", action="store_true", help="skip the extra one-image-per-UNet-batch measurement")
+    ap.add_argument("--ref-streams", dest="ref_streams", type=int, default=6, help="HIP streams of the one-image-per-UNet-batch measurement")
     ap.add_argument("--cpu-skip-vae", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--fp8-conv", dest="fp8_conv", action="store_true", help="bf16 mode with e4m3 ResBlock convolutions (FFN_FP8) as the timed configuration")
@@ -422,28 +431,35 @@ def main():
             import copy
             a1 = copy.copy(args)
             a1.batch = 1
+            # one image per UNet call leaves most of the chip idle (48 tiles of the 64x64-level GEMMs for 256 CUs), so this layout runs more
+            # HIP streams than the batched one (measured: 2 streams 2.04, 4: 2.01, 6: 2.37 images/s; the host threads are the limit)
+            n1 = max(args.ref_streams, len(models))
+            models1 = models + [add_sibling(model) for _ in range(n1 - len(models))]
+            streams1 = streams + [torch.cuda.Stream(device=device) for _ in range(n1 - len(streams))]
 
             def worker1(j):
                 torch.cuda.set_device(device)
-                with torch.cuda.stream(streams[j]):
+                with torch.cuda.stream(streams1[j]):
                     for i in range(ref_steps):
-                        edit_once(models[j], a1, 5000 + 10 * j + i)
-                streams[j].synchronize()
+                        edit_once(models1[j], a1, 5000 + 10 * j + i)
+                streams1[j].synchronize()
 
             ref_steps = 1
-            for j in range(len(models)):        # warm-up: graphs / tuning of the 2- and 3-row shapes
+            for j in range(n1):                 # warm-up: graphs / tuning of the 2- and 3-row shapes
                 worker1(j)
             ref_steps = 3
             torch.cuda.synchronize()
             t1 = time.time()
-            th = [threading.Thread(target=worker1, args=(j,)) for j in range(len(models))]
+            th = [threading.Thread(target=worker1, args=(j,)) for j in range(n1)]
             [t.start() for t in th]
             [t.join() for t in th]
             torch.cuda.synchronize()
-            v1 = ref_steps * len(models) / (time.time() - t1)
+            v1 = ref_steps * n1 / (time.time() - t1)
             line["config"]["reference_batch_layout"] = {
-                "value": round(v1, 4), "unit": "images/s", "images_per_unet_batch": 1, "unet_batch": 4, "concurrent_streams": args.concurrent,
-                "note": "same path, one image per UNet call (inversion B=2, guided B=4 logical / 3 physical rows)"}
+                "value": round(v1, 4), "unit": "images/s", "images_per_unet_batch": 1, "unet_batch": 4, "concurrent_streams": n1,
+                "note": "same path, one image per UNet call (inversion B=2, guided B=4 logical / 3 physical rows; the reference row re-enters at up_blocks[2])"}
+            del models1[len(models):], streams1[len(streams):]
+            torch.cuda.empty_cache()
         if not args.no_roofline:
             line["roofline"], table = roofline_leg(model, args)
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
