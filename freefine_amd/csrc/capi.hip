@@ -260,7 +260,8 @@ static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn, int splitk = 1) {
     const long lim = (1l << 31) - 4096;
     if (d.K % 64 != 0 || d.K < 128 || d.N % bn != 0 || d.M < bm) return false;
     const int osz = d.x3 ? 4 : 2;                                  // bytes per output / residual element
-    if (d.x3 && ((d.K / 3) % 64 != 0 || d.a_lo % 8 != 0)) return false;      // whole 64-element chunks in each of the three segments
+    if (d.x3 && (d.x3 != 2 || (d.K / 3) % 64 != 0 || d.a_lo % 8 != 0)) return false;      // chunk-ordered W, whole 64-element chunks
+    if (d.x3 && splitk > 1 && (d.K / 192) % splitk != 0) return false;                    // K slices of whole chunks (three K tiles each)
     if (splitk > 1) {       // split-K: raw fp32 slabs + igemm_splitk_reduce_kernel (which applies every plain epilogue option)
         if (!can_split(d) || (d.K / 64) % splitk != 0 || d.K / 64 / splitk < 2 || (long)splitk * d.M * d.N * 4 > d.ws_bytes || (long)splitk * d.M * d.N * 4 >= lim) return false;
     } else {
@@ -455,7 +456,7 @@ static TuneKey tune_key(const ffn_igemm_desc& d) {
     if (d.conv) { k.Cin = d.Cin; k.Hin = d.Hin; k.Win = d.Win; k.stride = d.stride; k.upsample = d.upsample; k.pad = d.pad; k.Hout = d.Hout; k.Wout = d.Wout; }
     k.Kpad = d.Kpad;
     k.ldr = d.residual ? d.ldr : 0;
-    k.dtype = d.x3 ? FFN_BF16X3 : (d.f8 ? FFN_FP8 : FFN_BF16);
+    k.dtype = d.x3 ? (FFN_BF16X3 | (d.x3 << 8)) : (d.f8 ? FFN_FP8 : FFN_BF16);
     k.ptrs = (d.bias ? 1 : 0) | (d.rowbias ? 2 : 0) | (d.residual ? 4 : 0) | (d.ws && d.ws_bytes > 0 ? 8 : 0);
     const long per = (long)d.M * d.N * 4;
     k.wslabs = d.ws ? (int)(d.ws_bytes / per > 1024 ? 1024 : d.ws_bytes / per) : 0;      // how many split-K slabs the workspace holds
@@ -799,7 +800,7 @@ static int dispatch_igemm(hipStream_t s, const ffn_igemm_desc& d) {
 // the library's private view of a split-bf16 problem: the kernels and the tile / split-K logic see the VIRTUAL contraction 3K
 static ffn_igemm_desc x3_view(const ffn_igemm_desc& d) {
     ffn_igemm_desc v = d;
-    v.x3 = 1;
+    v.x3 = d.x3 == 2 ? 2 : 1;          // order of W's virtual contraction: 1 = plane, 2 = chunk (64-element chunks)
     v.f8 = 0;
     v.K = 3 * d.K;
     v.flags |= FFN_IG_OUT_F32;
@@ -868,6 +869,7 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
         const int plane = d->conv ? d->Cin : d->K;
         REQUIRE(d->a_lo % 8 == 0 && d->a_lo >= plane && d->a_lo + plane <= d->lda, "igemm: split-bf16 A needs planes of %d elements: a_lo=%d, lda=%d", plane, d->a_lo, d->lda);
         REQUIRE(d->lda % 8 == 0, "igemm: lda=%d must be a multiple of 8", d->lda);
+        if (d->x3 == 2) REQUIRE(plane % 64 == 0, "igemm: chunk-ordered split-bf16 weights need K (conv: Cin) %% 64 == 0 (%d)", plane);
         REQUIRE(d->alpha == 1.0f, "igemm: split-bf16 problems take alpha = 1");
         if (d->residual) REQUIRE(aligned16(d->residual), "igemm: fp32 residual must be 16-byte aligned");
     }

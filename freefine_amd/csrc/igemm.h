@@ -333,7 +333,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // X3 (FFN_BF16X3, "split-bf16"): every fp32 value is carried as hi + lo (two bf16) and a product as hi*hi + hi*lo + lo*hi on the bf16
 // MFMA with fp32 accumulation.  Nothing changes in the multiplier: the GEMM simply runs over a VIRTUAL contraction of 3K --
 //   A: pair-format rows [hi(0..K) ... | lo at column a_lo ...] read as segments [A_hi | A_hi | A_lo]   (p.K holds 3K, Kr = K)
-//   W: packed [N][3K] = [W_hi | W_lo | W_hi] (conv: per tap), plain rows
+//   W: packed [N][3K] = [W_hi | W_lo | W_hi] (conv: per tap), plain rows -- "plane order" (p.x3 == 1), or, where K (conv: Cin) is a
+//      multiple of 64, "chunk order" (p.x3 == 2): that triple per 64-element chunk, which lets the ping-pong kernel stage each half tile once
 // so only the loader's K -> (tap, column) map differs.  Output / residual are fp32 (epilogue instantiated for float).
 // F8 (FFN_FP8): A and W hold OCP e4m3 bytes; the library hands the kernels a bf16-SHAPED view of the problem (K, Cin, lda, Kpad in units of
 // two bytes), so nothing in the addressing changes -- only the multiply (mma_fp8: two fp8 MFMAs per 16-byte chunk pair) and the scale
@@ -420,7 +421,10 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
         const bool kin = kk < p.K;
         if (AMODE == AMODE_DENSE) {
             int ka = kk;
-            if (X3) {                             // segment 0, 1: hi plane; segment 2: lo plane (a chunk never straddles: Kr % 8 == 0)
+            if (X3 && p.x3 == 2) {                // chunk order: [hi(64) | lo(64) | hi(64)] of W per 64-element chunk of K; A: hi, hi, lo
+                const int blk = kk / 192, w = kk - blk * 192, seg = w >> 6;
+                ka = blk * 64 + (w & 63) + (seg == 2 ? p.a_lo : 0);
+            } else if (X3) {                      // plane order: segment 0, 1: hi plane; segment 2: lo plane (a chunk never straddles: Kr % 8 == 0)
                 const int seg = (kk >= Kr) + (kk >= 2 * Kr);
                 ka = kk - seg * Kr + (seg == 2 ? p.a_lo : 0);
             }
@@ -432,7 +436,12 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
             }
         } else {
             int tap, ci;
-            if (X3) {
+            if (X3 && p.x3 == 2) {
+                const int c3 = 3 * p.Cin;
+                tap = kk / c3;
+                const int r = kk - tap * c3, blk = r / 192, w = r - blk * 192, seg = w >> 6;
+                ci = blk * 64 + (w & 63) + (seg == 2 ? p.a_lo : 0);
+            } else if (X3) {
                 const int c3 = 3 * p.Cin;
                 tap = kk / c3;
                 const int r = kk - tap * c3;

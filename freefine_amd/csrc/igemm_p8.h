@@ -71,10 +71,20 @@ __device__ __forceinline__ void pp_barrier() {
 #ifdef PP_TRACE
 __device__ unsigned long long pp_trace[256 * 64];   // tools/native/pp_bench.hip: 100 MHz timestamps around the low-row stores of each tile
 #endif
-// X3 (FFN_BF16X3, split-bf16 operands; see igemm.h): the multiplier is untouched -- the K-tile stream simply runs over the virtual
-// contraction [A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi] (p.K = 3 x the real K; per conv tap), which is a different SCALAR K
-// position per K tile (k_position) and a pixel stride of p.lda instead of Cin.  Output and residual are fp32: accumulators start at
-// bias + row bias + fp32 residual, the epilogue stores 16 bytes per lane through the same lane permutation as the split-K slabs.
+// X3 (FFN_BF16X3, split-bf16 operands; see igemm.h): the multiplier is untouched -- the K-tile stream runs over the virtual contraction
+// of 3 K in CHUNK order (p.x3 == 2): every 64-element chunk c of the real contraction contributes three consecutive K tiles
+//     T0 = A_hi[c] x W_hi[c]      T1 = A_hi[c] x W_lo[c]      T2 = A_lo[c] x W_hi[c]
+// (W is packed in exactly that order, so its K position stays linear; A's is a scalar function of the K-tile counter).  Consecutive tiles
+// share an operand, so each of the four half tiles is STAGED ONCE per chunk instead of six stagings: the two A slots and the two B slots of
+// the LDS double buffer are assigned separately --
+//     A_hi[c] -> A slot 0 (read by T0, T1; re-staged during T2)          A_lo[c] -> A slot 1 (read by T2; re-staged during the next T1)
+//     W_hi[c] -> B slot c & 1 (read by T0, T2)                            W_lo[c] -> the other B slot (read by T1)
+// which keeps every re-staging >= 2 phases behind the slot's last read (the WAR rule above) -- and a tile only requests what the NEXT tile
+// does not already have: T2 requests A_hi and W_hi of the next chunk (the full set), T0 only W_lo (B pieces: phases 1-2, then nothing; its
+// phase-4 wait is vmcnt(0)), T1 only A_lo (A pieces: phases 3-4; its phase-1 wait is vmcnt(0)).  18 instead of 27 LDS-DMA pieces per chunk
+// and wave in a kernel whose bound is the issue of those pieces.  K slices of a split-K launch are whole chunks.
+// Output and residual are fp32: accumulators start at bias + row bias + fp32 residual, the epilogue stores 16 bytes per lane through the
+// same lane permutation as the split-K slabs.
 // F8 (FFN_FP8, 3x3 convolutions): fp8 e4m3 operands in the bf16 byte geometry (the library passes a bf16-shaped view: K, Cin, Kpad in
 // two-byte units), so a K tile carries 128 real elements and each fragment pair takes TWO fp8 MFMAs -- twice the MFMA work per LDS-DMA
 // piece of a kernel whose bound is the issue of those pieces.  Operands are pre-scaled by powers of two (activations 2^4, weights per
@@ -164,8 +174,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     // (the nine taps of a chunk back to back) and (ky, chunk, kx) -- and both run 5-13 % SLOWER (310 / 313 vs 289 us at M = 196608,
     // Cin = 320; 373 vs 339 us at 32x32 x 640): the launch is not bound by where its lines come from, and the strided walks lose more
     // (requests to lines still in flight, weight rows no longer streamed) than the L2 hits return.
-    // X3: a tap's K tiles are [cptr hi chunks (x W_hi) | the same cptr hi chunks (x W_lo) | cptr lo chunks (x W_hi)]; a dense problem
-    // is one "tap" of cptr = K / 64 chunks.  The 20-bit reciprocal is exact while kt * cpt < 2^20 (kt < 9 cpt, cpt < 341).
+    // X3: a tap is 3 cptr K tiles (three per 64-element chunk, see the header); a dense problem is one "tap" of cptr = K / 64 chunks.
+    // The 20-bit reciprocal is exact while kt * cpt < 2^20 (kt < 9 cpt, cpt < 341).
     const int cptr = AMODE == AMODE_DENSE ? (X3 ? p.K / 192 : 1) : p.Cin / 64;      // real 64-element chunks per tap
     const int cpt = X3 ? 3 * cptr : cptr;
     const int cpt_rcp = X3 ? ((1 << 20) + cpt - 1) / cpt : (65536 + cpt - 1) / cpt;
@@ -173,11 +183,11 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     int ka = 0, tap_ky = 0, tap_kx = 0, tap_off = 0;  // of K tile l_kt; set by k_position()
     auto k_position = [&]() {
         const int kt = l_k0 + l_kt;
-        if constexpr (X3) {
+        if constexpr (X3) {                           // chunk order: tile r of a tap = (chunk r / 3, segment r % 3); segments 0, 1 read the hi plane, 2 the lo plane
             const int tap = AMODE == AMODE_DENSE ? 0 : (kt * cpt_rcp) >> 20;
             const int r = kt - tap * cpt;
-            const int seg = (r >= cptr) + (r >= 2 * cptr);
-            ka = (r - seg * cptr) * 128 + (seg == 2 ? lo_bytes : 0);
+            const int c = (r * 21846) >> 16;
+            ka = c * 128 + (r - 3 * c == 2 ? lo_bytes : 0);
             if (AMODE != AMODE_DENSE) {
                 tap_ky = (tap * 21846) >> 16;
                 tap_kx = tap - 3 * tap_ky;
@@ -560,15 +570,29 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
 
     int c_tile = first, c_kt = 0, buf = 0;
     int p_tile = -1;                                  // tile whose high rows still sit in the accumulators (-1: none)
+    int ty = 0, cp = 0;                               // X3: segment of this K tile (0, 1, 2) and parity of its chunk along the stream
     for (int s = 0; s < S; ++s) {
         const bool more = s + 1 < S;                  // another K tile follows in this workgroup's stream: request it during this one
         const int nb = buf ^ 1;
+        // LDS slots this tile READS its A / B fragments from (ra, rb), slots the next tile's operands are STAGED into (la, lb), and which
+        // of the two the next tile still needs (plain kernels: both, the other buffer)
+        int ra = buf, rb = buf, la = nb, lb = nb;
+        bool needA = more, needB = more;
+        if constexpr (X3) {
+            const int nty = ty == 2 ? 0 : ty + 1, ncp = ty == 2 ? cp ^ 1 : cp;
+            ra = ty == 2 ? 1 : 0;
+            rb = ty == 1 ? cp ^ 1 : cp;
+            la = nty == 2 ? 1 : 0;
+            lb = nty == 1 ? ncp ^ 1 : ncp;
+            needA = more && nty != 1;
+            needB = more && nty != 2;
+        }
 
         // ---- phase 1: low rows, k-substep 0 ----
         __builtin_amdgcn_sched_barrier(0);
         if (p_tile < 0) {
-            read_a(buf, a_rd0, 0);
-            read_b(buf, b_rd0);
+            read_a(ra, a_rd0, 0);
+            read_b(rb, b_rd0);
         }
         if (p_tile >= 0) {
             // first K tile of a new output tile (never the last K tile of the stream: nk >= 2).  The previous tile's high rows, final
@@ -577,20 +601,20 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
             // in flight, so no wait of the K loop ever sits behind a store's round trip.  Queue, oldest first:
             //   A-high of this K tile | next tile's column vectors | low stores | high stores | B x NB1
             // (the residual loads of init_rows are the compiler's: it drains the counter at their first use)
-            store_rows(p_tile, I4_t{});
+            store_rows(p_tile, I4_t{});                // (X3: the first K tile of an output tile is a T0: the next tile needs its B pieces)
 #pragma unroll
-            for (int i = 0; i < NB1; ++i) issue_b(i, nb);
+            for (int i = 0; i < NB1; ++i) issue_b(i, lb);
             pp_wait_vmcnt<NB1 + 2 * NST>();           // through A-high
             init_rows(c_tile, I0_t{});
             __builtin_amdgcn_sched_barrier(0);        // the fragment reads last: their registers are free for the epilogue's temporaries
-            read_a(buf, a_rd0, 0);
-            read_b(buf, b_rd0);
-        } else if (more) {
+            read_a(ra, a_rd0, 0);
+            read_b(rb, b_rd0);
+        } else if (needB) {
 #pragma unroll
-            for (int i = 0; i < NB1; ++i) issue_b(i, nb);
+            for (int i = 0; i < NB1; ++i) issue_b(i, lb);
             pp_wait_vmcnt<NB1>();                     // A-high of THIS K tile (requested in phase 4 of the previous one) has landed
         } else {
-            pp_wait_vmcnt<0>();
+            pp_wait_vmcnt<0>();                       // last K tile of the stream, or an X3 T1 (nothing requested for it after the previous tile's wait)
         }
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
@@ -599,10 +623,10 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         pp_barrier();
 
         // ---- phase 2: high rows, k-substep 0 ----
-        read_a(buf, a_rd0, FH);
-        if (more) {
+        read_a(ra, a_rd0, FH);
+        if (needB) {
 #pragma unroll
-            for (int i = NB1; i < FN; ++i) issue_b(i, nb);
+            for (int i = NB1; i < FN; ++i) issue_b(i, lb);
         }
         if (p_tile >= 0) {                            // the high rows of the new tile start
             init_rows(c_tile, I4_t{});
@@ -615,12 +639,12 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         pp_barrier();
 
         // ---- phase 3: low rows, k-substep 1 ----
-        read_a(buf, a_rd1, 0);
-        read_b(buf, b_rd1);
-        if (more) {
+        read_a(ra, a_rd1, 0);
+        read_b(rb, b_rd1);
+        if (needA) {
             k_position();
-            issue_a(0, nb);
-            issue_a(1, nb);
+            issue_a(0, la);
+            issue_a(1, la);
         }
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
@@ -629,14 +653,17 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         pp_barrier();
 
         // ---- phase 4: high rows, k-substep 1 ----
-        read_a(buf, a_rd1, FH);
+        read_a(ra, a_rd1, FH);
         if (more) {
+            if (needA) {
 #pragma unroll
-            for (int i = 2; i < NA; ++i) issue_a(i, nb);
+                for (int i = 2; i < NA; ++i) issue_a(i, la);
+            }
             advance();
             // B and A-low of the next K tile have landed (this phase's A-high pieces, and the next output tile's 6 column-vector
             // loads, may still be in flight)
             if (PP_ABL == 9 && c_kt < 2) {}           // timing experiment: no wait in the two K tiles behind the stores (results garbage)
+            else if (!needA) pp_wait_vmcnt<0>();      // X3 T0: only B pieces were requested (phases 1-2); the loader never switches output tiles here
             else if (switched) pp_wait_vmcnt<NA - 2 + (SPLIT ? 0 : 6)>();
             else pp_wait_vmcnt<NA - 2>();
         }
@@ -656,6 +683,9 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         pp_barrier();
 
         buf = nb;
+        if constexpr (X3) {
+            if (ty == 2) { ty = 0; cp ^= 1; } else ++ty;
+        }
         if (++c_kt == nk) {                           // output tile complete (high rows are stored in the next K tile's phase 2, or below)
             p_tile = c_tile;
             c_kt = 0;

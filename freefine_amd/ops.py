@@ -86,13 +86,13 @@ def _igemm_name(lib, dcode, d):
 # ---------------------------------------------------------------------------------------------------------------
 # weight packing (host side, once at load time)
 # ---------------------------------------------------------------------------------------------------------------
-def _mark_x3(t):
-    t._ffn_x3 = True          # linear() / conv3x3() recognise a split-bf16 weight by this tag and run the FFN_BF16X3 path
-    return t
+def _mark_x3(t, order=1):
+    t._ffn_x3 = order         # linear() / conv3x3() recognise a split-bf16 weight by this tag and run the FFN_BF16X3 path
+    return t                  # (1 = plane order [hi | lo | hi] over the whole K / tap, 2 = chunk order: that triple per 64-element chunk)
 
 
 def is_x3(w):
-    return getattr(w, "_ffn_x3", False)
+    return bool(getattr(w, "_ffn_x3", 0))
 
 
 def split_hi_lo(w):
@@ -109,7 +109,10 @@ def pack_linear(w, dtype, x3=False):
     if x3:
         assert k % 8 == 0, f"split-bf16 weights need K % 8 == 0 (K={k})"
         hi, lo = split_hi_lo(w)
-        return _mark_x3(torch.cat([hi, lo, hi], dim=1).contiguous())
+        if k % 64 == 0:       # chunk order (what the ping-pong tile takes: each half tile staged once per chunk)
+            hc, lc = hi.reshape(n, k // 64, 64), lo.reshape(n, k // 64, 64)
+            return _mark_x3(torch.stack([hc, lc, hc], dim=2).reshape(n, 3 * k).contiguous(), 2)
+        return _mark_x3(torch.cat([hi, lo, hi], dim=1).contiguous(), 1)
     ks = kstage(dtype)
     kpad = (k + ks - 1) // ks * ks
     out = torch.zeros(n, kpad, dtype=dtype, device=w.device)
@@ -126,7 +129,10 @@ def pack_conv3x3(w, dtype, cin_pad=None, x3=False):
     if x3:
         assert cp % 8 == 0, f"split-bf16 conv weights need Cin % 8 == 0 (Cin={cp})"
         hi, lo = split_hi_lo(w2.reshape(cout, 9, cp))
-        return _mark_x3(torch.cat([hi, lo, hi], dim=2).reshape(cout, 27 * cp).contiguous())
+        if cp % 64 == 0:
+            hc, lc = hi.reshape(cout, 9, cp // 64, 64), lo.reshape(cout, 9, cp // 64, 64)
+            return _mark_x3(torch.stack([hc, lc, hc], dim=3).reshape(cout, 27 * cp).contiguous(), 2)
+        return _mark_x3(torch.cat([hi, lo, hi], dim=2).reshape(cout, 27 * cp).contiguous(), 1)
     return pack_linear(w2.reshape(cout, 9 * cp), dtype)
 
 
@@ -238,6 +244,7 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
     d.M, d.N, d.K, d.Kpad = M, N, K, w.stride(0)    # Kpad = row stride of W (an activation view can serve as W)
     d.lda = xa.stride(-2) if xa.ndim > 1 else xa.shape[-1]
     d.a_lo = K if x3 else 0
+    d.x3 = int(w._ffn_x3) if x3 else 0
     odt = torch.float32 if x3 else x.dtype          # element type of out / residual
     d.rows_per_batch = rows_per_batch or M
     d.ldrb = rowbias.stride(0) if rowbias is not None else 0
@@ -309,6 +316,7 @@ def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, ou
     d.M, d.N, d.K, d.Kpad = B * Hout * Wout, N, 9 * Cin, w.shape[1]
     d.lda = 2 * Cin if x3 else Cin
     d.a_lo = Cin if x3 else 0
+    d.x3 = int(w._ffn_x3) if x3 else 0
     d.rows_per_batch = Hout * Wout
     d.ldrb = (rowbias_ld or rowbias.stride(0)) if rowbias is not None else 0
     if out is None:

@@ -68,7 +68,8 @@ typedef struct ffn_igemm_desc {
     void* ws;         /* optional fp32 scratch for split-K partial slabs (>= splitk*M*N*4 bytes) or NULL */
     long ws_bytes;
     int a_lo;         /* FFN_BF16X3: column (conv: channel) offset of the lo plane inside a row (pixel) of A; else ignored */
-    int x3;           /* set by the library from `dtype` (callers leave it 0) */
+    int x3;           /* FFN_BF16X3: order of W's virtual contraction -- 0 / 1 = plane order [W_hi | W_lo | W_hi] over the whole K (conv: tap);
+                         2 = chunk order: that triple per 64-element chunk (needs K, conv: Cin, % 64 == 0; what the ping-pong tile takes) */
     int f8;           /* set by the library from `dtype` (callers leave it 0) */
 } ffn_igemm_desc;
 int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
@@ -78,7 +79,8 @@ int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
  * MFMA), dropped term a_lo*w_lo ~ 2^-18.  Operand formats:
  *   A    bf16 PAIR rows: hi plane at columns [0, K), lo plane at [a_lo, a_lo + K) of the same row (lda = row stride in bf16
  *        elements; conv: per input pixel, planes of Cin channels, lda = elements per pixel) -- ffn_split_pair writes it from fp32;
- *   W    bf16 [N][Kpad], Kpad >= 3K: [W_hi | W_lo | W_hi] (conv: that triple per tap, k' = (tap*3 + seg)*Cin + ci);
+ *   W    bf16 [N][Kpad], Kpad >= 3K: [W_hi | W_lo | W_hi] (conv: that triple per tap, k' = (tap*3 + seg)*Cin + ci) -- or, desc.x3 = 2,
+ *        the triple per 64-element chunk (k' = ((tap*Cin/64 + chunk)*3 + seg)*64 + e), which the ping-pong kernel needs;
  *   out, residual   fp32 (FFN_IG_OUT_F32 is implied); bias / rowbias fp32 as always; GEGLU, SILU, transposed output, split-K as in bf16.
  * K in the descriptor is the REAL contraction length (dense K, conv 9*Cin). */
 int ffn_split_pair(void* stream, const float* src, void* dst, long rows, int C, int ld_src);
