@@ -37,6 +37,8 @@ F_TCA = 72.5e9         # one extra attention pass in blocks 10-15 per sample-for
 F_VAE = 7.26e12        # 2 encodes + 2 decodes @512^2
 F_VAE_ENC, F_VAE_DEC = 1.117e12, 2.515e12
 F_UNET_PHASE_A = 0.4396e12   # conv_in + down blocks + mid block + up_blocks[0..1] of one sample-forward (FlopCounterMode on the oracle UNet)
+F_REF_TAIL = 57.8e9     # what a reference row runs behind the K / V projection of transformer block 15: both TCA passes of that block's self attention
+                        # (2 x 21.5 GFLOP at S = 4096, C = 320) + to_out, cross attention, feed-forward, proj_out, conv_out (14.8 GFLOP)
 
 
 def synth_inputs(idx=0):
@@ -401,6 +403,8 @@ def main():
         # reference-stream reuse: each reference row skips conv_in ... up_blocks[1] (439.6 of the 804.3 GFLOP of a sample-forward)
         reuse_on = bool(getattr(model, "reuse_ref_stream", False)) and model.unet.reuse_replays > 0
         skipped = (rows_g - 2) * F_UNET_PHASE_A if reuse_on else 0.0
+        if reuse_on and getattr(model, "drop_ref_tail", False):      # every guided step but the last: the reference rows stop after block 15's K / V
+            skipped += (rows_g - 2) * F_REF_TAIL * (n - 1) / n
         f_exec = n * ((2 + rows_g) * F_UNET - skipped + rows_g * F_TCA) + 2 * F_VAE_ENC + (1 if args.batch > 1 else 2) * F_VAE_DEC
         value = world * args.steps * args.concurrent * args.batch / dt
         line = {
@@ -416,7 +420,8 @@ def main():
                        "images_per_unet_batch": args.batch, "unet_batch": 4 * args.batch, "hip_graph": not args.no_graph,
                        "exact_row_dedup": model.dedup_rows and "on: the duplicated reference row of the CFG batch is evaluated once (3 physical rows), outputs unchanged",
                        "reference_stream_reuse": ("on: the guided loop's reference row re-enters at up_blocks[2] from the state the inversion pass recorded for the "
-                                                  "same (latent, timestep, prompt); outputs unchanged") if reuse_on else "off",
+                                                  "same (latent, timestep, prompt) and, at every step but the last, stops behind block 15's K / V projection (its eps is dead there); "
+                                                  "outputs unchanged") if reuse_on else "off",
                        "vae_decode": "batched path decodes the edited latent only (the reference decodes the reference stream too and drops it unless return_ori)" if args.batch > 1 else "both streams, like the reference",
                        "algorithmic_tflop_per_image": round(f_img / 1e12, 1),
                        "whole_path_tflops_per_gpu": round(f_img * value / world / 1e12, 1),

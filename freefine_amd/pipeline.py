@@ -59,6 +59,7 @@ class FreeFinePipeline:
         # exact: the guided loop's reference row re-enters the UNet from the state the inversion pass recorded for the same (latent,
         # timestep, "") triple instead of being recomputed from conv_in (HipUNet.forward, `reuse`); off = recompute like the reference
         self.reuse_ref_stream = True
+        self.drop_ref_tail = True    # with reuse: reference rows stop after the last K / V projection at every step but the last (their eps is dead)
         self._ref_cache = None
 
     # ------------------------------------------------------------------------------------------------------------
@@ -140,7 +141,7 @@ class FreeFinePipeline:
         separate HIP streams; give it its own controller with register_attention_control*."""
         other = FreeFinePipeline(self.unet.share(), self.vae, self.tokenizer, self.text_encoder,
                                  DDIMScheduler.from_config(self.scheduler.config), self.device)
-        other.noise_device, other.dedup_rows, other.reuse_ref_stream = self.noise_device, self.dedup_rows, self.reuse_ref_stream
+        other.noise_device, other.dedup_rows, other.reuse_ref_stream, other.drop_ref_tail = self.noise_device, self.dedup_rows, self.reuse_ref_stream, self.drop_ref_tail
         return other
 
     def _seed(self, seed):
@@ -433,7 +434,10 @@ class FreeFinePipeline:
             if cache is not None:
                 slot = cache["slots"][n_act - (i - start_step) - 1]
                 nr = sum(ref_flags)
-                reuse = dict(mode="replay", join=cache["join"], ref=ref_flags, state=[s.repeat_interleave(nr, 0) for s in slot] if nr > 1 else slot)
+                # every step but the last overwrites the reference latent before anything reads it (`latents[1:] = ref_latent` above):
+                # the reference rows' eps is dead there and their tail behind the last K / V projection is not run
+                reuse = dict(mode="replay", join=cache["join"], ref=ref_flags, state=[s.repeat_interleave(nr, 0) for s in slot] if nr > 1 else slot,
+                             drop_tail=self.drop_ref_tail and i + 1 < len(self.scheduler.timesteps))
             if row_map is None:
                 noise_pred = self.unet(torch.cat([latents] * 2), t, encoder_hidden_states=text, reuse=reuse)
             else:
@@ -881,7 +885,10 @@ class FreeFinePipeline:
             if cache is not None:        # the reference rows re-enter from the state inversion step n - k - 1 recorded (same latent, timestep, prompt)
                 slot = cache["slots"][n_act - (i - start_step) - 1]
                 nr = sum(ref_flags)
-                reuse = dict(mode="replay", join=cache["join"], ref=ref_flags, state=[s.repeat_interleave(nr, 0) for s in slot] if nr > 1 else slot)
+                # every step but the last overwrites the reference latent before anything reads it (`latents[1:] = ref_latent` above):
+                # the reference rows' eps is dead there and their tail behind the last K / V projection is not run
+                reuse = dict(mode="replay", join=cache["join"], ref=ref_flags, state=[s.repeat_interleave(nr, 0) for s in slot] if nr > 1 else slot,
+                             drop_tail=self.drop_ref_tail and i + 1 < len(self.scheduler.timesteps))
             eps = self.unet(latents.index_select(0, lat_idx), t, encoder_hidden_states=text_phys, row_map=row_map, reuse=reuse)
             eps = eps.view(K, 4, *init.shape[1:])
             new = torch.empty_like(latents)

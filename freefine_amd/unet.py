@@ -240,8 +240,10 @@ class HipUNet:
         logical batch, its pass tables are translated, and the result is expanded back to the logical batch.
         reuse (optional, see above): dict(mode="record", join=j) -> after the call `self.last_boundary` holds the tensors at the
         entrance of up block j ([x, skip, skip, ...], all physical rows); dict(mode="replay", join=j, ref=[bool per physical row
-        of ONE image], state=[tensors [n_ref_rows, HW, C] ...]) -> rows flagged `ref` skip everything before up block j and
-        continue from `state` (their eps rows are still produced: the remaining blocks run on all rows)."""
+        of ONE image], state=[tensors [n_ref_rows, HW, C] ...], drop_tail=bool) -> rows flagged `ref` skip everything before up block j
+        and continue from `state`; the remaining blocks run on all rows.  drop_tail: the caller does not read the reference rows' eps
+        (every guided step but the last overwrites their latent, model.py:582-586) -> those rows stop after the K / V projection of the
+        last transformer block, the last thing any other row reads of them, and their eps rows come back as zeros."""
         sample = sample.to(self.device, torch.float32).contiguous()
         B = sample.shape[0]
         self._row_map = tuple(row_map) if row_map is not None else None
@@ -264,7 +266,7 @@ class HipUNet:
         # advances its counters exactly as an eager forward would); the plans' fingerprint is part of the graph key
         state = [(c.cur_att_layer, c.cur_step) for c in ctrls]
         fp = self._plan_all(B, sample.shape[2], sample.shape[3])
-        rsig = None if ru is None else (ru["mode"], ru["join"], ru.get("ref"), tuple(tuple(t.shape) for t in ru.get("state", ())))
+        rsig = None if ru is None else (ru["mode"], ru["join"], ru.get("ref"), bool(ru.get("drop_tail")), tuple(tuple(t.shape) for t in ru.get("state", ())))
         sig = (B, tuple(sample.shape), tuple(enc.shape), fp, self._row_map, len(ctrls), rsig)
         g = self._graphs.get(sig)
         if g is None:
@@ -307,6 +309,7 @@ class HipUNet:
                             perm.append(a0 + ia); ia += 1
                 ent = self._reuse_idx[key] = (torch.tensor(idx_a, device=self.device), torch.tensor(perm, device=self.device))
             ru["idx_a"], ru["perm"] = ent
+            ru["idx_a_list"] = [i * Bp + p for i in range(K) for p in ru["sel"]]
             ck = (id(enc), enc._version, key)
             ea = self._enc_a.get(ck)
             if ea is None or ea[0]() is not enc:
@@ -411,7 +414,7 @@ class HipUNet:
     def _ctrl_key(self, B, H, W):
         """everything a forward's attention plans depend on (masks by identity + in-place version)"""
         ru = self._reuse
-        key = [self.hook, B, H, W, self._row_map, None if ru is None or ru["mode"] != "replay" else (ru["join"], ru["ref"])]
+        key = [self.hook, B, H, W, self._row_map, None if ru is None or ru["mode"] != "replay" else (ru["join"], ru["ref"], bool(ru.get("drop_tail")))]
         for c in self._ctrls():
             mv = tuple((m.data_ptr(), m._version) if torch.is_tensor(m) else None
                        for m in (c.fg_retain_mask, c.fg_ref_mask, c.local_edit_region, c.src_masks, c.tgt_masks))
@@ -442,9 +445,15 @@ class HipUNet:
         fps = []
         ru = self._reuse
         join_tb = self.join_block_tb(ru["join"]) if (ru is not None and ru["mode"] == "replay") else -1
-        for ci, (is_cross, place, S, heads) in enumerate(self._call_list(H, W)):
+        calls = self._call_list(H, W)
+        drop = ru is not None and ru["mode"] == "replay" and bool(ru.get("drop_tail"))
+        for ci, (is_cross, place, S, heads) in enumerate(calls):
             self._in_phase_a = ci // 2 < join_tb             # phase A of a replayed forward: the non-reference rows only
+            if drop and ci == len(calls) - 1:                 # dropped tail: the last block's cross attention runs on the non-reference rows
+                self._in_phase_a = True
             plan = self._plan(is_cross, place, B, S, heads)
+            if drop and ci == len(calls) - 2:                 # ... and its self attention has no reference QUERY rows
+                plan = self._without_ref_queries(plan, B)
             if plan["passes"] is None:
                 fps.append(0)
                 continue
@@ -507,12 +516,26 @@ class HipUNet:
             x = ops.linear(x, r.sc[0], r.sc[1], K=cin)
         return ops.conv3x3(h, r.c2[0], r.c2[1], B, H, W, r.cout, residual=x, out=out)
 
-    def _attention(self, t, is_cross, place, q, k, vt, ldq_view, B, S, Sk):
+    def _without_ref_queries(self, plan, B):
+        """the plan of a self-attention call over all B physical rows, restricted to the output rows that are not reference rows (dropped
+        tail of a replayed forward): entries keep naming physical Q / K / V rows; the tiled-head rule stays pinned to the row it had"""
+        keep = self._reuse["idx_a_list"]
+        passes = plan["passes"] if plan["passes"] is not None else [[ops.AttnEntrySpec(b, b) for b in range(B)]]
+        pin = lambda e, r: e if (e is None or e.hr_row is not None) else ops.AttnEntrySpec(e.q_row, e.kv_row, e.w_const, e.w_slope, e.wq, e.kmask, e.qsel, e.flags, r)
+        out = dict(plan)
+        out["passes"] = [[pin(rows[r], r) for r in keep] for rows in passes]
+        return out
+
+    def _attention(self, t, is_cross, place, q, k, vt, ldq_view, B, S, Sk, drop_ref_queries=False):
         D = t.C // t.heads
         scale = D ** -0.5
         if self.controller is None:
-            return ops.attention(q, k, vt, t.heads, scale, None, Sk=Sk, C=t.C, x3=self.x3, out_pair=self.x3)
+            passes = [[ops.AttnEntrySpec(r, r, hr_row=r) for r in self._reuse["idx_a_list"]]] if drop_ref_queries else None
+            return ops.attention(q, k, vt, t.heads, scale, passes, Sk=Sk, C=t.C, x3=self.x3, out_pair=self.x3)
         plan = self._plan(is_cross, place, B, S, t.heads)
+        if drop_ref_queries:
+            assert plan["kind"] != "shared_kv"
+            plan = self._without_ref_queries(plan, B)
         if plan["kind"] == "shared_kv":
             rr = plan["ref_rows"]
             kc = k[..., :t.C] if k.shape[-1] != t.C else k
@@ -522,7 +545,9 @@ class HipUNet:
         return ops.attention(q, k, vt, t.heads, scale, plan["passes"], Sk=Sk, C=t.C, w_dev=self.cg_dev if plan["needs_cg"] else None, x3=self.x3,
                              out_pair=self.x3)
 
-    def _transformer_block(self, t, x, B, H, W, place, kv_text, out=None):
+    def _transformer_block(self, t, x, B, H, W, place, kv_text, out=None, drop=None):
+        """drop (dropped tail of a replayed forward, last block only) = (device index of the rows that go on, their cross-attention K / V):
+        the reference rows stop once their K / V^T are projected"""
         S, C = H * W, t.C
         res0 = x
         h = self._gn(x, t.norm, 1e-6, False)
@@ -531,7 +556,11 @@ class HipUNet:
         y = ops.layernorm(h, *t.ln[0], pair=self.x3)
         qk = ops.linear(y, t.w_qk1, None, K=C)                                  # [B,S,2C]: q | k
         vt = ops.linear(y, t.w_v1, None, K=C, rows_per_batch=S, transposed_ld=(S + 7) // 8 * 8)   # V^T [B,C,S]
-        a = self._attention(t, False, place, qk, qk[..., C:], vt, 2 * C, B, S, S)
+        a = self._attention(t, False, place, qk, qk[..., C:], vt, 2 * C, B, S, S, drop_ref_queries=drop is not None)
+        if drop is not None:                                 # `a` already holds the surviving rows only; the residual streams follow
+            idx, kv_text = drop
+            h, res0, B = h.index_select(0, idx), res0.index_select(0, idx), idx.shape[0]
+            self._in_phase_a = True
         h = ops.linear(a, t.o1[0], t.o1[1], K=C, residual=h)
         # --- cross attention
         y = ops.layernorm(h, *t.ln[1], pair=self.x3)
@@ -607,7 +636,12 @@ class HipUNet:
                 dst = cat_dst(r.cout, H * W) if j + 1 < len(blk.res) else None      # the next resblock of this block concatenates again
                 x = self._resblock(r, x, B, H, W, temb_all, out=None if blk.attn else dst)
                 if blk.attn:
-                    x = self._transformer_block(blk.attn[j], x, B, H, W, "up", next(ti), out=dst)
+                    last = replay and bool(ru.get("drop_tail")) and blk.attn[j] is self.transformers[-1]
+                    drop = (ru["idx_a"], ru["text_kv_a"][-1]) if last else None
+                    x = self._transformer_block(blk.attn[j], x, B, H, W, "up", next(ti), out=dst, drop=drop)
+                    if last:                                  # from here on only the non-reference rows exist
+                        assert dst is None and i == len(self.up) - 1 and j == len(blk.res) - 1, "the last transformer block closes the network"
+                        B, temb_all = x.shape[0], temb_full[:x.shape[0]]
             if blk.up is not None:
                 C = x.shape[-1]
                 x = ops.conv3x3(x, blk.up[0], blk.up[1], B, H, W, C, upsample=True, out=cat_dst(C, 4 * H * W))
@@ -615,4 +649,8 @@ class HipUNet:
         C = x.shape[-1]
         x = self._gn(x, self.norm_out, cfg.norm_eps, True)
         eps = ops.conv3x3(x, self.conv_out[0], self.conv_out[1], B, H, W, C, out_f32=True)
-        return ops.nhwc_to_nchw_f32(eps, cfg.out_channels, H, W)
+        eps = ops.nhwc_to_nchw_f32(eps, cfg.out_channels, H, W)
+        self._in_phase_a = False
+        if B != BB:                                           # dropped tail: the reference rows' eps is not computed (zeros)
+            eps = torch.zeros(BB, *eps.shape[1:], dtype=eps.dtype, device=eps.device).index_copy_(0, ru["idx_a"], eps)
+        return eps

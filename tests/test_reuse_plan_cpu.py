@@ -78,6 +78,33 @@ def test_replay_index_maps_and_phase_tables():
     assert ru["idx_a"].tolist() == [0, 2, 4, 6] and ru["perm"].tolist() == [0, 4, 1, 5, 2, 6, 3, 7]
 
 
+def test_dropped_tail_keeps_reference_keys_but_not_reference_queries():
+    """every guided step but the last: the reference rows stop after the K / V projection of the last transformer block -- its self
+    attention keeps reading their K / V (physical rows) but has no output row for them, the tiled-head rule stays pinned"""
+    net = _net()
+    c = _controller(net)
+    net._row_map = (0, 1, 2, 1)
+    ru = net._prepare_reuse(dict(mode="replay", join=2, ref=(False, True, False), state=[torch.zeros(1, 1, 1)], drop_tail=True), 3, torch.randn(3, 77, 64))
+    assert ru["idx_a_list"] == [0, 2]
+    net._reuse = ru
+    c.cur_att_layer = 30                                    # self-attention of block 15
+    plan = net._without_ref_queries(net._plan(False, "up", 3, 256, 2), 3)
+    assert [len(r) for r in plan["passes"]] == [2, 2]
+    assert [(e.q_row, e.kv_row, e.hr_row) for e in plan["passes"][0]] == [(0, 1, 0), (2, 1, 2)]
+    assert [(e.q_row, e.kv_row) for e in plan["passes"][1]] == [(0, 0), (2, 2)]
+    # a plain (unmodulated) call: explicit one-pass table over the surviving rows, head rule pinned to the physical row
+    plain = net._without_ref_queries(dict(kind="passes", passes=None, needs_cg=False), 3)
+    assert [(e.q_row, e.kv_row, e.hr_row) for e in plain["passes"][0]] == [(0, 0, 0), (2, 2, 2)]
+    # the fingerprint of a dropped-tail forward differs from the full one's in exactly the last two attention calls
+    fps = {}
+    for drop in (False, True):
+        ru["drop_tail"] = drop
+        c.cur_att_layer, c.cur_step = 0, 0
+        fps[drop] = net._plan_all_slow(3, 16, 16)[1]
+    assert fps[False][:-2] == fps[True][:-2] and fps[False][-2] != fps[True][-2] and fps[False][-1] != fps[True][-1]
+    assert len(fps[True][-2][2][0]) == 2 and len(fps[True][-1][2][0]) == 2 and len(fps[False][-2][2][0]) == 3
+
+
 def test_phase_a_rejects_terms_that_reach_a_reference_row():
     e = ops.AttnEntrySpec(0, 1)
     try:
