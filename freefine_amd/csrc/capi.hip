@@ -13,6 +13,7 @@
 #include "attention_pp.h"
 #include "attention_x.h"
 #include "attention_x3.h"
+#include "attention_x3p.h"
 #include "elementwise.h"
 #include "igemm.h"
 #include "igemm_p8.h"
@@ -1010,7 +1011,9 @@ extern "C" int ffn_attn_kernel_name(int dtype, const ffn_attn_desc* d, char* buf
     REQUIRE(d && buf && len > 0, "attn_kernel_name: null argument");
     int dp = 0, qf = 0;
     if (dtype == FFN_BF16X3 && d->D <= 64) {
-        snprintf(buf, len, "void attn_x3_kernel<%s>(ffn_attn_desc)", attn_has_masks(*d) ? "true" : "false");
+        bool masks, pp;
+        attn_bf16_choice(*d, &masks, &pp);
+        snprintf(buf, len, "void %s<%s>(ffn_attn_desc)", pp ? "attn_x3p_kernel" : "attn_x3_kernel", attn_has_masks(*d) ? "true" : "false");
         return FFN_OK;
     }
     if (dtype == FFN_BF16X3) dtype = FFN_F32;
@@ -1049,6 +1052,19 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
         constexpr int lds = 2 * (4 * 8192) + 8 * 4 * 2 * 64 * 16;
         dim3 grid(((d->S + 255) / 256) * d->heads * d->Bo);
         int rc;
+        bool masks_pp, pp;
+        attn_bf16_choice(*d, &masks_pp, &pp);      // the ping-pong schedule has the same preconditions as attn_pp_kernel's (d = 64, Sk % 64 == 0, S >= 128, ...)
+        if (pp) {
+            constexpr int lds = 5 * (2 * 8192) + 8 * 4 * 2 * 64 * 16;      // K ring of 2 + V^T ring of 3 [hi | lo] images, multi-pass sums
+            if (attn_has_masks(*d)) {
+                if ((rc = set_lds(attn_x3p_kernel<true>, lds))) return rc;
+                LAUNCH(attn_x3p_kernel<true>, grid, dim3(512), lds, s, *d);
+            } else {
+                if ((rc = set_lds(attn_x3p_kernel<false>, lds))) return rc;
+                LAUNCH(attn_x3p_kernel<false>, grid, dim3(512), lds, s, *d);
+            }
+            return check_launch("attn(split-bf16, ping-pong)");
+        }
         if (attn_has_masks(*d)) {
             if ((rc = set_lds(attn_x3_kernel<true>, lds))) return rc;
             LAUNCH(attn_x3_kernel<true>, grid, dim3(512), lds, s, *d);

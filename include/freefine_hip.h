@@ -160,7 +160,9 @@ typedef struct ffn_attn_desc {
 } ffn_attn_desc;
 int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d);
 /* dtype FFN_BF16X3: q / k / vt / out are fp32 exactly as with FFN_F32; head sizes D <= 64 run attn_x3_kernel (attention_x3.h: both
- * products in split-bf16 arithmetic, three bf16 MFMAs per term, fp32 softmax), larger heads fall back to the exact fp32 kernel. */
+ * products in split-bf16 arithmetic, three bf16 MFMAs per term, fp32 softmax) -- or, under attn_pp_kernel's preconditions (D = 64,
+ * Sk % 64 == 0, S >= 128, no uniform-softmax entry), attn_x3p_kernel (attention_x3p.h: the same arithmetic in the ping-pong schedule;
+ * FFN_ATTN_PP=0 disables it too); larger heads fall back to the exact fp32 kernel. */
 /* bf16 launches with D = 64, Sk % 64 == 0, S >= 128 and no degenerate (uniform-softmax) entry run attn_pp_kernel (attention_pp.h:
  * software-pipelined, 8 waves in two alternating groups); everything else attn_kernel (attention.h).  Same results up to fp32
  * summation order.  FFN_ATTN_PP=0 in the environment forces attn_kernel.

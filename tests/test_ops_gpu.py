@@ -954,6 +954,41 @@ def test_x3_attention_uniform_wq_and_determinism(gpu):
         assert torch.equal(ops.attention(q, k, vt, heads, scale, [p0, p1], Sk=Sk, x3=True), out)
 
 
+@pytest.mark.parametrize("S,Sk,heads", [(128, 64, 2), (256, 192, 5), (384, 1024, 3), (1000, 320, 2)])
+def test_x3_attention_pingpong_schedule(gpu, S, Sk, heads):
+    """attn_x3p_kernel (d = 64, Sk % 64 == 0, S >= 128): one key tile, an odd tile count, a ragged last query block, K / V rows that differ
+    from the Q rows, two passes with a key mask + query selector + per-query weight and a skipped entry, fp32 and pair-form output,
+    bit-for-bit repeatability (the double-buffered LDS images are rewritten one phase before they are read)."""
+    from freefine_amd import ops
+    from freefine_amd import _lib as L
+    g = torch.Generator().manual_seed(S + Sk)
+    dt, D, B = torch.float32, 64, 3
+    Cc = heads * D
+    q, k, v = rnd((B, S, Cc), dt, gpu, g), rnd((2, Sk, Cc), dt, gpu, g), rnd((2, Sk, Cc), dt, gpu, g)
+    vt = ops.transpose(v, ld_dst=Sk)
+    scale = D ** -0.5
+    km = (torch.rand(Sk, generator=g) > 0.5).to(torch.uint8).to(gpu)
+    qs = (torch.rand(S, generator=g) > 0.4).to(torch.uint8).to(gpu)
+    wq = torch.rand(S, generator=g).to(gpu)
+    cg = torch.tensor([0.3], device=gpu)
+    p0 = [ops.AttnEntrySpec(0, 1, 0.0, 1.0, kmask=km, qsel=qs), ops.AttnEntrySpec(1, 0, 1.0, 0.0), ops.AttnEntrySpec(2, 1, 1.0, 0.0, wq=wq)]
+    p1 = [ops.AttnEntrySpec(0, 0, 1.0, -1.0), None, ops.AttnEntrySpec(1, 0, 0.5, 0.0)]
+    out = ops.attention(q, k, vt, heads, scale, [p0, p1], Sk=Sk, w_dev=cg, x3=True)
+    qc, kc, vc = q.double(), k.double(), v.double()
+    allowed = (km[None, :] != 0) == (qs[:, None] != 0)
+    ref0 = 0.3 * _ref_attention_gpu(qc[0], kc[1], vc[1], heads, scale, [allowed] * heads) + 0.7 * _ref_attention_gpu(qc[0], kc[0], vc[0], heads, scale)
+    ref1 = _ref_attention_gpu(qc[1], kc[0], vc[0], heads, scale)
+    ref2 = wq.double()[:, None] * _ref_attention_gpu(qc[2], kc[1], vc[1], heads, scale) + 0.5 * _ref_attention_gpu(qc[1], kc[0], vc[0], heads, scale)
+    errs = [relerr(out[0], ref0), relerr(out[1], ref1), relerr(out[2], ref2)]
+    print(f"x3 ping-pong attention S={S} Sk={Sk} h={heads}: {max(errs):.2e}")
+    assert max(errs) < X3_TOL
+    pair = ops.attention(q, k, vt, heads, scale, [p0, p1], Sk=Sk, w_dev=cg, x3=True, out_pair=True)
+    assert pair.dtype == torch.bfloat16 and pair.shape == (B, S, 2 * Cc)
+    assert relerr(pair[..., :Cc].double() + pair[..., Cc:].double(), out.double()) < 2e-5
+    for _ in range(3):
+        assert torch.equal(ops.attention(q, k, vt, heads, scale, [p0, p1], Sk=Sk, w_dev=cg, x3=True), out)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # FFN_FP8: e4m3 operands for the 3x3 convolutions of the bf16 fast mode.  The GEMM is exact on its quantised operands up to fp32
 # accumulation and the bf16 output rounding, so the kernel tests quantise on the host and compare against the fp64 convolution of the
