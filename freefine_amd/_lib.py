@@ -9,7 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FREEFINE_HIP_LIB") or os.path.join(_HERE, "libfreefine_hip.so")   # env override: A/B builds of the same ABI
 
 FFN_F32, FFN_BF16, FFN_BF16X3, FFN_FP8 = 0, 1, 2, 3
-IG_OUT_SILU, IG_OUT_F32, IG_GEGLU, IG_OUT_TRANSPOSED, IG_OUT_PAIR = 1, 2, 4, 8, 16
+IG_OUT_SILU, IG_OUT_F32, IG_GEGLU, IG_OUT_TRANSPOSED, IG_OUT_PAIR, IG_OUT_GELU, IG_OUT_RELU = 1, 2, 4, 8, 16, 32, 64
+ELT_RELU, ELT_ADD = 0, 1
 ATT_MAXP, ATT_MAXB = 4, 16
 ATT_HEAD_RULE, ATT_UNIFORM_SEL1, ATT_UNIFORM_SEL0 = 1, 2, 4
 NORM_SILU, NORM_OUT_PAIR = 1, 2
@@ -106,6 +107,8 @@ SYMBOLS = {
     "ffn_timestep_embed": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i]),
     "ffn_transpose": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
     "ffn_cast": (_i, [_vp, _i, _i, _vp, _vp, _l]),
+    "ffn_eltwise": (_i, [_vp, _i, _i, _vp, _vp, _vp, _l]),
+    "ffn_resize_bilinear": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "ffn_image_to_nhwc": (_i, [_vp, _i, _vp, _vp, _l, _i]),
     "ffn_nhwc_to_image": (_i, [_vp, _i, _vp, _vp, _i, _i, _i]),
 }

@@ -888,7 +888,7 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
     }
     if (d->flags & FFN_IG_OUT_TRANSPOSED) {
         REQUIRE(d->ldo % 4 == 0, "igemm: transposed ldo=%d must be a multiple of 4", d->ldo);
-        REQUIRE(!(d->flags & (FFN_IG_GEGLU | FFN_IG_OUT_F32 | FFN_IG_OUT_SILU)) && !d->residual && !d->rowbias,
+        REQUIRE(!(d->flags & (FFN_IG_GEGLU | FFN_IG_OUT_F32 | FFN_IG_OUT_SILU | FFN_IG_OUT_GELU | FFN_IG_OUT_RELU)) && !d->residual && !d->rowbias,
                 "igemm: transposed output supports bias only");
     } else {
         REQUIRE(d->N % 4 == 0 && d->ldo % 4 == 0, "igemm: N=%d and ldo=%d must be multiples of 4", d->N, d->ldo);
@@ -899,8 +899,12 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
         }
         if (d->flags & FFN_IG_GEGLU) {
             REQUIRE(d->N % 64 == 0, "igemm: GEGLU needs N %% 64 == 0 (N=%d)", d->N);
-            REQUIRE(!d->residual && !d->rowbias && !(d->flags & (FFN_IG_OUT_F32 | FFN_IG_OUT_SILU)), "igemm: GEGLU epilogue is exclusive");
+            REQUIRE(!d->residual && !d->rowbias && !(d->flags & (FFN_IG_OUT_F32 | FFN_IG_OUT_SILU | FFN_IG_OUT_GELU | FFN_IG_OUT_RELU)), "igemm: GEGLU epilogue is exclusive");
         }
+    }
+    {
+        const int act = d->flags & (FFN_IG_OUT_SILU | FFN_IG_OUT_GELU | FFN_IG_OUT_RELU);
+        REQUIRE((act & (act - 1)) == 0, "igemm: SILU / GELU / RELU are mutually exclusive");
     }
     if (d->ws) REQUIRE(aligned16(d->ws) && d->ws_bytes >= 0, "igemm: workspace must be 16-byte aligned");
     REQUIRE(d->splitk >= 0, "igemm: splitk must be >= 0");
@@ -1103,6 +1107,42 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
         if (D <= 160) return masks ? launch_attn<bf16, 160, 1, 64, 1, true>(s, *d) : launch_attn<bf16, 160, 1, 64, 1, false>(s, *d);
     }
     return fail(FFN_ENOSYS, "attn: head dim %d not supported (max 160; use the GEMM path)", D);
+}
+
+// ---- elementwise / resampling helpers of the depth front end ----------------------------------------------------------
+extern "C" int ffn_eltwise(void* stream, int dtype, int op, const void* a, const void* b, void* y, long n) {
+    REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "eltwise: bad dtype %d", dtype);
+    REQUIRE(op == FFN_ELT_RELU || op == FFN_ELT_ADD, "eltwise: bad op %d", op);
+    REQUIRE(a && y && (op != FFN_ELT_ADD || b), "eltwise: null operand");
+    REQUIRE(n > 0 && n % 4 == 0, "eltwise: n=%ld must be a positive multiple of 4", n);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long n4 = n / 4;
+    const int grid = grid_for(n4);
+    if (dtype == FFN_F32) {
+        if (op == FFN_ELT_RELU) LAUNCH((eltwise_kernel<float, FFN_ELT_RELU>), dim3(grid), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)y, n4);
+        else LAUNCH((eltwise_kernel<float, FFN_ELT_ADD>), dim3(grid), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)y, n4);
+    } else {
+        if (op == FFN_ELT_RELU) LAUNCH((eltwise_kernel<bf16, FFN_ELT_RELU>), dim3(grid), dim3(256), 0, s, (const bf16*)a, (const bf16*)b, (bf16*)y, n4);
+        else LAUNCH((eltwise_kernel<bf16, FFN_ELT_ADD>), dim3(grid), dim3(256), 0, s, (const bf16*)a, (const bf16*)b, (bf16*)y, n4);
+    }
+    return check_launch("eltwise");
+}
+extern "C" int ffn_resize_bilinear(void* stream, int dtype, const void* x, void* y, int B, int Hin, int Win, int Hout, int Wout, int C, int relu) {
+    REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "resize_bilinear: bad dtype %d", dtype);
+    REQUIRE(x && y, "resize_bilinear: null operand");
+    REQUIRE(B > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && C > 0 && C % 4 == 0, "resize_bilinear: bad shape (C=%d must be a multiple of 4)", C);
+    REQUIRE((long)B * Hout * Wout * C < (1l << 40) && (long)Hin * Win < (1l << 31), "resize_bilinear: problem too large");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long n4 = (long)B * Hout * Wout * (C / 4);
+    const int grid = grid_for(n4);
+    if (dtype == FFN_F32) {
+        if (relu) LAUNCH((resize_bilinear_kernel<float, true>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, n4, Hin, Win, Hout, Wout, C);
+        else LAUNCH((resize_bilinear_kernel<float, false>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, n4, Hin, Win, Hout, Wout, C);
+    } else {
+        if (relu) LAUNCH((resize_bilinear_kernel<bf16, true>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, n4, Hin, Win, Hout, Wout, C);
+        else LAUNCH((resize_bilinear_kernel<bf16, false>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, n4, Hin, Win, Hout, Wout, C);
+    }
+    return check_launch("resize_bilinear");
 }
 
 // ---- norms -------------------------------------------------------------------------------------------------------

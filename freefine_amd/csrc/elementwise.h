@@ -178,3 +178,57 @@ __global__ __launch_bounds__(256) void nhwc_to_image_kernel(const T* __restrict_
         dst[i] = fminf(fmaxf(v, 0.f), 1.f);
     }
 }
+
+// ---- depth front end ----------------------------------------------------------------------------------------
+// y = max(a, 0) / y = a + b, four elements per thread-iteration (depth_anything/blocks.py:68, 137-139)
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void eltwise_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float va[4], vb[4];
+        load4(a + 4 * i, va);
+        if (OP == FFN_ELT_ADD) {
+            load4(b + 4 * i, vb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) va[r] += vb[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) va[r] = fmaxf(va[r], 0.f);
+        }
+        store4(y + 4 * i, va);
+    }
+}
+
+// bilinear resampling, align_corners = True, NHWC (torch.nn.functional.interpolate as called by depth_anything/blocks.py:147-149 and
+// dpt.py:132, 165): source index = dst * (in - 1) / (out - 1) in fp32, the four taps blended as
+// h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11) -- the order of ATen's upsample_bilinear2d.  Four channels per thread.
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const T* __restrict__ x, T* __restrict__ y, long n4, int Hin, int Win, int Hout,
+                                                              int Wout, int C) {
+    const int c4 = C / 4;
+    const float sh = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
+    const float sw = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % c4) * 4;
+        long t = i / c4;
+        const int ox = (int)(t % Wout);
+        t /= Wout;
+        const int oy = (int)(t % Hout);
+        const long b = t / Hout;
+        const float fy = sh * oy, fx = sw * ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+        const float h1 = fy - y0, h0 = 1.f - h1, w1 = fx - x0, w0 = 1.f - w1;
+        const T* base = x + b * Hin * Win * (long)C + c;
+        float v00[4], v01[4], v10[4], v11[4], o[4];
+        load4(base + ((long)y0 * Win + x0) * C, v00);
+        load4(base + ((long)y0 * Win + x1) * C, v01);
+        load4(base + ((long)y1 * Win + x0) * C, v10);
+        load4(base + ((long)y1 * Win + x1) * C, v11);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o[r] = h0 * (w0 * v00[r] + w1 * v01[r]) + h1 * (w0 * v10[r] + w1 * v11[r]);
+            if (RELU) o[r] = fmaxf(o[r], 0.f);
+        }
+        store4(y + 4 * i, o);
+    }
+}

@@ -22,7 +22,15 @@
 #include "../../include/freefine_hip.h"
 
 enum { AMODE_DENSE = 0, AMODE_CONV3 = 1 };
-enum { IG_OUT_SILU = FFN_IG_OUT_SILU, IG_OUT_F32 = FFN_IG_OUT_F32, IG_GEGLU = FFN_IG_GEGLU, IG_OUT_TRANSPOSED = FFN_IG_OUT_TRANSPOSED, IG_OUT_PAIR = FFN_IG_OUT_PAIR };
+enum { IG_OUT_SILU = FFN_IG_OUT_SILU, IG_OUT_F32 = FFN_IG_OUT_F32, IG_GEGLU = FFN_IG_GEGLU, IG_OUT_TRANSPOSED = FFN_IG_OUT_TRANSPOSED, IG_OUT_PAIR = FFN_IG_OUT_PAIR,
+       IG_OUT_GELU = FFN_IG_OUT_GELU, IG_OUT_RELU = FFN_IG_OUT_RELU };
+// the plain epilogue's activation (flags are launch-uniform)
+__device__ __forceinline__ float ig_activation(float x, int flags) {
+    if (flags & IG_OUT_SILU) return silu_exact(x);
+    if (flags & IG_OUT_GELU) return gelu_erf(x);
+    if (flags & IG_OUT_RELU) return fmaxf(x, 0.f);
+    return x;
+}
 // four fp32 values -> the bf16 pair form (hi at p, lo at p + lo_off), 8 bytes each
 __device__ __forceinline__ void store_pair_row4(bf16* p, int lo_off, const float* v) {
     u32x2 hi, lo;
@@ -44,7 +52,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
     float* __restrict__ outF = reinterpret_cast<float*>(p.out);
     const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
     const bool out_f32 = p.flags & IG_OUT_F32;
-    const bool out_silu = p.flags & IG_OUT_SILU;
+    const bool out_act = p.flags & (IG_OUT_SILU | IG_OUT_GELU | IG_OUT_RELU);
 
     if (SWAP && gridDim.y > 1) {
         // split-K partial: raw fp32 accumulators to slab blockIdx.y of the workspace
@@ -104,7 +112,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
                             float x = acc[i][j][r] * p.alpha;
                             if (p.bias) x += p.bias[n + r];
                             if (p.rowbias) x += p.rowbias[(long)bb * p.ldrb + n + r];
-                            if (out_silu) x = silu_exact(x);
+                            if (out_act) x = ig_activation(x, p.flags);
                             v[r] = x;
                         }
                         if (res) {
@@ -797,7 +805,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmPar
             float x = a[r] * p.alpha;
             if (p.bias) x += p.bias[n + r];
             if (p.rowbias) x += p.rowbias[(long)bb * p.ldrb + n + r];
-            if (p.flags & IG_OUT_SILU) x = silu_exact(x);
+            x = ig_activation(x, p.flags);
             v[r] = x;
         }
         if (res) {

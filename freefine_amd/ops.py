@@ -224,7 +224,7 @@ def _workspace(device):
     return ws
 
 def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, rows_per_batch=None, silu=False,
-           geglu=False, out_f32=False, transposed_ld=None, alpha=1.0, splitk=0, out_pair=False):
+           geglu=False, out_f32=False, transposed_ld=None, alpha=1.0, splitk=0, out_pair=False, gelu=False, relu=False):
     """out = x @ w[:, :K]^T (+bias ...).  x: [..., K] contiguous rows (M = prod of leading dims)."""
     lib = L.load()
     K = K if K is not None else x.shape[-1]
@@ -252,6 +252,10 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
     n_out = N
     if silu:
         flags |= L.IG_OUT_SILU
+    if gelu:
+        flags |= L.IG_OUT_GELU
+    if relu:
+        flags |= L.IG_OUT_RELU
     if geglu:
         flags |= L.IG_GEGLU
         n_out = N // 2
@@ -289,7 +293,7 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
 
 
 def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, out=None, residual=None, rowbias=None,
-            rowbias_ld=None, out_f32=False, Hout=None, Wout=None, splitk=0):
+            rowbias_ld=None, out_f32=False, Hout=None, Wout=None, splitk=0, relu=False):
     """x: [B, Hin*Win, Cin] NHWC; w: packed [Cout, Kpad]; returns [B, Hout*Wout, Cout]."""
     lib = L.load()
     He, We = (Hin * 2, Win * 2) if upsample else (Hin, Win)
@@ -325,7 +329,7 @@ def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, ou
     d.ldr = residual.shape[-1] if residual is not None else 0
     d.Hin, d.Win, d.Cin, d.Hout, d.Wout = Hin, Win, Cin, Hout, Wout
     d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
-    d.flags, d.alpha, d.conv = (L.IG_OUT_F32 if out_f32 else 0), (w._ffn_f8[1] if f8 else 1.0), 1
+    d.flags, d.alpha, d.conv = (L.IG_OUT_F32 if out_f32 else 0) | (L.IG_OUT_RELU if relu else 0), (w._ffn_f8[1] if f8 else 1.0), 1
     d.splitk, d.ws, d.ws_bytes = splitk, _workspace(x.device).data_ptr(), WS_BYTES
     if _PROF is None:
         L.check(lib.ffn_igemm(_stream(), dcode, CT.byref(d)), "ffn_igemm(conv)")
@@ -622,6 +626,37 @@ def cast(src, dtype, out=None):
         out = torch.empty(src.shape, dtype=dtype, device=src.device)
     L.check(_timed(f"cast_kernel<{_tname(src)}, {_tname(out)}>", 0.0, float(src.numel() * (src.element_size() + out.element_size())),
                    lambda: lib.ffn_cast(_stream(), _dt(src), _dt(out), src.data_ptr(), out.data_ptr(), src.numel())), "ffn_cast")
+    return out
+
+
+def relu(x, out=None):
+    """max(x, 0) (fp32 / bf16, numel % 4 == 0)"""
+    lib = L.load()
+    out = torch.empty_like(x) if out is None else out
+    L.check(_timed("eltwise_kernel<relu>", 0.0, 2.0 * x.numel() * x.element_size(),
+                   lambda: lib.ffn_eltwise(_stream(), _dt(x), L.ELT_RELU, x.data_ptr(), None, out.data_ptr(), x.numel())), "ffn_eltwise")
+    return out
+
+
+def add(a, b, out=None):
+    """a + b (same shape and dtype, contiguous)"""
+    lib = L.load()
+    assert a.shape == b.shape and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+    out = torch.empty_like(a) if out is None else out
+    L.check(_timed("eltwise_kernel<add>", 0.0, 3.0 * a.numel() * a.element_size(),
+                   lambda: lib.ffn_eltwise(_stream(), _dt(a), L.ELT_ADD, a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel())), "ffn_eltwise")
+    return out
+
+
+def resize_bilinear(x, B, Hin, Win, Hout, Wout, relu=False):
+    """x: [B, Hin*Win, C] NHWC -> [B, Hout*Wout, C]; torch's bilinear interpolation with align_corners=True"""
+    lib = L.load()
+    C_ = x.shape[-1]
+    assert x.is_contiguous() and x.numel() == B * Hin * Win * C_
+    out = torch.empty(B, Hout * Wout, C_, dtype=x.dtype, device=x.device)
+    L.check(_timed("resize_bilinear_kernel", 0.0, (x.numel() + out.numel()) * x.element_size(),
+                   lambda: lib.ffn_resize_bilinear(_stream(), _dt(x), x.data_ptr(), out.data_ptr(), B, Hin, Win, Hout, Wout, C_, 1 if relu else 0)),
+            "ffn_resize_bilinear")
     return out
 
 

@@ -47,8 +47,11 @@ enum {
     FFN_IG_OUT_F32 = 1 << 1,
     FFN_IG_GEGLU = 1 << 2,         /* N = 2*Nout; 16-column blocks alternate hidden/gate; out = hidden * gelu(gate) */
     FFN_IG_OUT_TRANSPOSED = 1 << 3, /* out[b][n][s], row stride ldo, m = b*rows_per_batch + s (V^T for ffn_attn) */
-    FFN_IG_OUT_PAIR = 1 << 4        /* FFN_BF16X3 only: out is the bf16 PAIR form [M][ldo], hi at column n, lo at column ldo/2 + n -- the A operand
+    FFN_IG_OUT_PAIR = 1 << 4,       /* FFN_BF16X3 only: out is the bf16 PAIR form [M][ldo], hi at column n, lo at column ldo/2 + n -- the A operand
                                        of the next FFN_BF16X3 GEMM (the GEGLU projection feeding ff.net.2); no residual */
+    FFN_IG_OUT_GELU = 1 << 5,       /* out = gelu_erf(acc + bias) (+ residual): the MLP of the DINOv2 blocks (dinov2/layers/mlp.py:31-38) */
+    FFN_IG_OUT_RELU = 1 << 6        /* out = max(acc + bias, 0) (+ residual): the DPT head's ResidualConvUnit / output convs (depth_anything/blocks.py:68-78,
+                                       dpt.py:93-98).  SILU / GELU / RELU are mutually exclusive and exclude GEGLU and the transposed output */
 };
 typedef struct ffn_igemm_desc {
     const void* A;        /* dense: [M][lda];  conv: NHWC input [B][Hin][Win][Cin] */
@@ -172,6 +175,16 @@ int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d);
 int ffn_attn_variant(int dtype, int D, int* dp, int* qf);
 /* the kernel instantiation ffn_attn launches for this problem, spelled like rocprofv3's kernel trace */
 int ffn_attn_kernel_name(int dtype, const ffn_attn_desc* d, char* buf, int len);
+
+/* ---- elementwise / resampling helpers of the depth front end ------------------------------------------ */
+/* y = max(a, 0) (FFN_ELT_RELU, b ignored) or y = a + b (FFN_ELT_ADD) over n elements (n % 4 == 0; fp32 or bf16).  Replaces the
+ * activation in front of ResidualConvUnit.conv1 and FeatureFusionBlock's skip_add (depth_anything/blocks.py:68, 137-139). */
+enum { FFN_ELT_RELU = 0, FFN_ELT_ADD = 1 };
+int ffn_eltwise(void* stream, int dtype, int op, const void* a, const void* b, void* y, long n);
+/* bilinear resampling of an NHWC tensor [B][Hin][Win][C] -> [B][Hout][Wout][C] with align_corners = True (source coordinate
+ * y * (Hin - 1) / (Hout - 1), fp32 weights; Hout == 1 reads row 0): torch.nn.functional.interpolate(mode="bilinear",
+ * align_corners=True) as called by depth_anything/blocks.py:147-149 and dpt.py:132, 165.  relu != 0 applies max(., 0) (dpt.py:166). */
+int ffn_resize_bilinear(void* stream, int dtype, const void* x, void* y, int B, int Hin, int Win, int Hout, int Wout, int C, int relu);
 
 /* ---- normalisation ------------------------------------------------------------------------------------------- */
 /* `silu` of ffn_groupnorm / ffn_gn_apply is a flag word: FFN_NORM_SILU applies SiLU; FFN_NORM_OUT_PAIR (fp32 input only) writes y as the

@@ -184,3 +184,22 @@ def test_g7_vae_vs_intree_ldm_encoder_decoder():
     x, z = rng_tensor(51, (2, 3, 64, 48)), rng_tensor(52, (2, 4, 8, 6))
     assert (vae.encoder(x) - torch.from_numpy(g["moments"])).abs().max().item() < 2e-5
     assert (vae.decoder(z) - torch.from_numpy(g["dec"])).abs().max().item() < 5e-5
+
+
+def test_g8_depth_network_vs_reference_dinov2_and_dpt_head():
+    """oracle/dpt.py (DINOv2 ViT + DPT head + the forward of DPT_DINOv2) against outputs of the reference's own modules
+    (torchhub/facebookresearch_dinov2_main/vision_transformer.py, depth_anything/dpt.py:22-167) on seeded weights: a square input at the
+    positional embedding's own grid, non-square inputs (bicubic interpolation of the positional embedding), two encoder sizes."""
+    from oracle import dpt as OD
+    g = np.load(os.path.join(GOLD, "g8_dpt.npz"))
+    for name, img_size, sizes in (("tiny", 70, ((70, 70), (56, 98))), ("mini", 518, ((42, 70),))):
+        cfg = OD.dpt_config(name)
+        cfg.img_size = img_size
+        st = OD.dpt_synthetic_state(cfg, seed=3 + len(name))
+        for (H, W) in sizes:
+            x = rng_tensor(80 + H + W, (2, 3, H, W))
+            feats = OD.vit_features(cfg, st, x, 4)
+            d = OD.depth_forward(cfg, st, x)
+            key = f"{name}_{H}x{W}"
+            assert (feats[3][0] - torch.from_numpy(g[key + "_feat3"])).abs().max().item() < 2e-5, key
+            assert d.shape == (2, H, W) and (d - torch.from_numpy(g[key + "_depth"])).abs().max().item() < 2e-5, key

@@ -559,8 +559,54 @@ def run_g7():
           f"decoder {dd:.3e} (|y|max {d_ref.abs().max():.3f})")
 
 
+# --------------------------------------------------------------------------------------------------------------
+# G8: the depth network of the 3D front end -- the reference's own DinoVisionTransformer + DPTHead / DPT_DINOv2.forward
+# --------------------------------------------------------------------------------------------------------------
+def run_g8():
+    """oracle/dpt.py against depth_anything/dpt.py (DPTHead, the forward of DPT_DINOv2: dpt.py:155-167) on the in-tree DINOv2
+    (torchhub/facebookresearch_dinov2_main/vision_transformer.py), seeded weights, two small encoders, a square input at the
+    pos-embed's own grid (no interpolation) and non-square inputs (bicubic pos-embed interpolation, offset 0.1)."""
+    hub = os.path.join(RH.REF, "torchhub", "facebookresearch_dinov2_main")
+    for q in (hub, RH.REF):
+        if q not in sys.path:
+            sys.path.insert(0, q)
+    import vision_transformer as vits
+    from depth_anything.dpt import DPTHead
+    import torch.nn.functional as F
+    from oracle import dpt as OD
+    out = {}
+    for name, img_size, sizes in (("tiny", 70, ((70, 70), (56, 98))), ("mini", 518, ((42, 70),))):
+        cfg = OD.dpt_config(name)
+        cfg.img_size = img_size
+        st = OD.dpt_synthetic_state(cfg, seed=3 + len(name))
+        vit = vits.DinoVisionTransformer(img_size=img_size, patch_size=14, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+                                         mlp_ratio=cfg.mlp_ratio, init_values=1.0, ffn_layer="mlp", block_chunks=0, num_register_tokens=0,
+                                         interpolate_antialias=False, interpolate_offset=0.1).eval()
+        head = DPTHead(1, cfg.embed_dim, cfg.features, False, out_channels=list(cfg.out_channels), use_clstoken=False).eval()
+        missing, unexpected = vit.load_state_dict({k[len("pretrained."):]: v for k, v in st.items() if k.startswith("pretrained.")}, strict=True)
+        assert not missing and not unexpected
+        missing, unexpected = head.load_state_dict({k[len("depth_head."):]: v for k, v in st.items() if k.startswith("depth_head.")}, strict=True)
+        assert not missing and not unexpected
+        for (H, W) in sizes:
+            x = rng_tensor(80 + H + W, (2, 3, H, W))
+            with torch.no_grad():                               # DPT_DINOv2.forward, dpt.py:155-167
+                feats = vit.get_intermediate_layers(x, 4, return_class_token=True)
+                d = head(feats, H // 14, W // 14)
+                d = F.relu(F.interpolate(d, size=(H, W), mode="bilinear", align_corners=True)).squeeze(1)
+                o_feats = OD.vit_features(cfg, st, x, 4)
+                o_d = OD.depth_forward(cfg, st, x)
+            df = max((a[0] - b[0]).abs().max().item() for a, b in zip(feats, o_feats))
+            dd = (d - o_d).abs().max().item()
+            key = f"{name}_{H}x{W}"
+            out[key + "_feat3"] = feats[3][0].numpy()
+            out[key + "_depth"] = d.numpy()
+            print(f"[G8] {key}: oracle vs reference  ViT features max abs diff {df:.3e} (|y|max {feats[3][0].abs().max():.3f}), "
+                  f"depth {dd:.3e} (|y|max {d.abs().max():.3f}, {float((d > 0).float().mean()):.2f} of the pixels positive)")
+    np.savez_compressed(os.path.join(GOLD, "g8_dpt.npz"), **out)
+
+
 if __name__ == "__main__":
-    only = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g6b", "g7"]
+    only = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g6b", "g7", "g8"]
     torch.set_grad_enabled(False)
     A, Mo = RH.import_reference()
     if "g1" in only:
@@ -577,3 +623,5 @@ if __name__ == "__main__":
         run_g6b()
     if "g7" in only:
         run_g7()
+    if "g8" in only:
+        run_g8()
