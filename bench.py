@@ -477,11 +477,15 @@ def main():
         if not args.no_fp8_leg and not args.fp8_conv and world == 1 and args.dtype == "bf16":
             # the same number for the plain bf16 engine on ONE stream, so that the fp8 figure has its like-for-like neighbour
             rec = fp8_leg(args, device)
-            t0 = time.time()
-            with torch.cuda.stream(streams[0]):
-                edit_once(models[0], args, 9000)
-            streams[0].synchronize()
-            rec["bf16_same_layout"] = round(args.batch / (time.time() - t0), 4)
+            best = None
+            for i in range(2):                                  # like fp8_leg: the second of two runs (the first may re-capture graphs)
+                torch.cuda.synchronize()
+                t0 = time.time()
+                with torch.cuda.stream(streams[0]):
+                    edit_once(models[0], args, 9000 + i)
+                streams[0].synchronize()
+                best = time.time() - t0
+            rec["bf16_same_layout"] = round(args.batch / best, 4)
             line["fp8_conv"] = rec
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline_leg(args)

@@ -139,13 +139,26 @@ class HipDepthAnything:
         hit = self._pos[key] = (cls_row, patch_pos[0].to(self.dtype).contiguous())
         return hit
 
+    @staticmethod
+    def _im2col(x, ps):
+        """[B, 3, H, W] -> [B * (H/ps) * (W/ps), 3 * ps * ps]: one row per patch (row-major over the patch grid), columns ordered (channel, ky, kx)
+        like patch_embed.proj.weight.reshape(C, -1) (patch_embed.py:75: Conv2d(kernel = stride = patch))"""
+        B, Cc, H, W = x.shape
+        ph, pw = H // ps, W // ps
+        return x.reshape(B, Cc, ph, ps, pw, ps).permute(0, 2, 4, 1, 3, 5).reshape(B * ph * pw, Cc * ps * ps)
+
+    @staticmethod
+    def _pixel_shuffle(y, B, H, W, k, cout):
+        """GEMM output [B, H*W, (dy, dx, co)] of a ConvTranspose2d(kernel = stride = k) -> NHWC rows [B, (H k)(W k), co]"""
+        return y.view(B, H, W, k, k, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, H * k * W * k, cout).contiguous()
+
     def _tokens(self, x):
         """patch embedding (a GEMM over the im2col view of the image, positional embedding added as the GEMM's residual) + class row"""
         cfg = self.cfg
         B, _, H, W = x.shape
         ps = cfg.patch
         ph, pw = H // ps, W // ps
-        cols = x.to(self.device, torch.float32).reshape(B, 3, ph, ps, pw, ps).permute(0, 2, 4, 1, 3, 5).reshape(B * ph * pw, 3 * ps * ps)
+        cols = self._im2col(x.to(self.device, torch.float32), ps)
         a = torch.zeros(B * ph * pw, self.kpe, dtype=self.dtype, device=self.device)
         a[:, :cols.shape[1]] = cols.to(self.dtype)
         cls_row, pos = self._pos_tokens(H, W)
@@ -184,8 +197,7 @@ class HipDepthAnything:
     def _up(self, x, B, H, W, dc):
         w, b, cin, cout, k = dc
         y = ops.linear(x, w, b, K=cin)                                               # [B, H*W, k*k*cout]
-        y = y.view(B, H, W, k, k, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, H * k * W * k, cout)      # pixel shuffle (plumbing)
-        return y.contiguous(), H * k, W * k
+        return self._pixel_shuffle(y, B, H, W, k, cout), H * k, W * k
 
     def _rcu(self, u, x, B, H, W, extra=None):
         """ResidualConvUnit (blocks.py:68-83): conv2(relu(conv1(relu(x)))) + x (+ extra: the fusion block's other input)"""

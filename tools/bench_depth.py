@@ -1,5 +1,5 @@
 """Throughput of the depth network on one GPU, with the oracle timed on the host cores beside it:
-    python tools/bench_depth.py [--encoder vitl] [--size 518] [--batch 4] [--steps 10] [--dtype bf16|f32] [--no-cpu-baseline]
+    python tools/bench_depth.py [--encoder vitl] [--size 518] [--batch 4] [--steps 10] [--dtype bf16|f32] [--no-cpu-baseline] [--kernel-table FILE]
 Prints one JSON line (depth maps / s; whole-network algorithmic FLOPs against the dense MFMA peak of the dtype)."""
 import argparse
 import json
@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", default="", help="write the per-kernel event table (HIP events around every launch of one forward) to this file")
     a = ap.parse_args()
     from freefine_amd.depth import HipDepthAnything, depth_config
     from oracle import dpt as OD                      # (weights generator + the CPU baseline; not on the timed GPU path)
@@ -68,6 +69,16 @@ def main():
             "ms_per_batch": round(dt_s * 1e3, 2), "batch": a.batch, "dtype": a.dtype, "data": "synthetic (seeded random weights)",
             "algorithmic_gflop_per_image": round(fl / 1e9, 1), "tflops": round(fl * a.batch / dt_s / 1e12, 1),
             "frac_of_mfma_peak": round(fl * a.batch / dt_s / 1e12 / peak, 4)}
+    if a.kernel_table:
+        from freefine_amd import ops
+        ops.profile_begin()
+        net(x)
+        rec = ops.profile_end()
+        with open(a.kernel_table, "w") as f:
+            f.write("kernel\tcalls\ttotal_ms\talgorithmic_TFLOP/s\talgorithmic_GB/s\n")
+            for k, v in sorted(rec.items(), key=lambda kv: -kv[1]["total_ms"]):
+                ms = max(v["total_ms"], 1e-9)
+                f.write(f"{k}\t{v['calls']}\t{v['total_ms']:.3f}\t{v['flops'] / ms / 1e9:.1f}\t{v['bytes'] / ms / 1e6:.1f}\n")
     if not a.no_cpu_baseline:
         torch.set_num_threads(max(8, min(32, torch.get_num_threads())))
         xc = x[:1].cpu()
