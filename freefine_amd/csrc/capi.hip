@@ -266,7 +266,9 @@ static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn, int splitk = 1) {
     if (splitk > 1) {       // split-K: raw fp32 slabs + igemm_splitk_reduce_kernel (which applies every plain epilogue option)
         if (!can_split(d) || (d.K / 64) % splitk != 0 || d.K / 64 / splitk < 2 || (long)splitk * d.M * d.N * 4 > d.ws_bytes || (long)splitk * d.M * d.N * 4 >= lim) return false;
     } else {
-        if ((d.alpha != 1.0f && !d.f8) || (d.flags & ~(FFN_IG_GEGLU | (d.x3 ? (FFN_IG_OUT_F32 | FFN_IG_OUT_PAIR) : 0)))) return false;
+        // GELU / RELU: applied by the plain bf16 epilogue, whose accumulators start at the bias -- not beside a residual (it starts there too)
+        const int act_ok = (!d.residual && !d.x3 && !d.f8 && !(d.flags & FFN_IG_GEGLU)) ? (FFN_IG_OUT_GELU | FFN_IG_OUT_RELU) : 0;
+        if ((d.alpha != 1.0f && !d.f8) || (d.flags & ~(FFN_IG_GEGLU | act_ok | (d.x3 ? (FFN_IG_OUT_F32 | FFN_IG_OUT_PAIR) : 0)))) return false;
         if (d.f8 && (!d.conv || (d.flags & FFN_IG_GEGLU))) return false;
         if (d.x3 && ((d.flags & FFN_IG_GEGLU) != 0) != ((d.flags & FFN_IG_OUT_PAIR) != 0)) return false;      // the split-bf16 GEGLU tile writes the pair form, nothing else does
         if ((d.flags & FFN_IG_GEGLU) && bn != 256) return false;

@@ -514,6 +514,20 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (!RES && !F8) {                  // plain epilogue activations (the accumulators started at the bias): the DINOv2 MLP's GELU, the DPT head's ReLU
+            if (p.flags & (FFN_IG_OUT_GELU | FFN_IG_OUT_RELU)) {
+                const bool gelu = p.flags & FFN_IG_OUT_GELU;
+#pragma unroll
+                for (int i = i0; i < i0 + FH; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu ? gelu_erf_fast(acc[i][j][r]) : fmaxf(acc[i][j][r], 0.f);
+                        asm volatile("" : "+v"(acc[i][j]));      // (plain registers in front of the pack / lane permutation, like the fp8 un-scale)
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         constexpr int NOF = FN;                       // output fragments per fragment row
         const int voff8 = (pr * p.ldo + 4 * pg) * 2;
         const int voff16 = pr * p.ldo * 2 + pg * 16;

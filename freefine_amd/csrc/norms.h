@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             float t = f[e] * sc[e] + sh[e];
-            if (SILU) t = silu_exact(t);
+            if (SILU) t = silu_for<T>(t);          // bf16 activations: the fast form (common.h); fp32 (parity / split-bf16 modes): exact
             f[e] = t;
         }
         if constexpr (PAIR) store_pair4(reinterpret_cast<bf16*>(y), pix, C, cc * EPC, f);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void gn_apply_f8_kernel(const bf16* __restrict
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float t = f[e] * sc[e] + sh[e];
-                if (SILU) t = silu_exact(t);
+                if (SILU) t = silu_fast(t);
                 f[e] = t * qs;
             }
 #pragma unroll
@@ -233,8 +233,8 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const T* __restrict__ x,
         float a = DT<T>::ld(x + off) * sc0 + (beta[c] - mean * sc0);
         float d = DT<T>::ld(x + off + 1) * sc1 + (beta[c + 1] - mean * sc1);
         if (SILU) {
-            a = silu_exact(a);
-            d = silu_exact(d);
+            a = silu_for<T>(a);
+            d = silu_for<T>(d);
         }
         if constexpr (PAIR) {
             bf16* yp = reinterpret_cast<bf16*>(y);

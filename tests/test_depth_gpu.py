@@ -59,6 +59,41 @@ def test_new_epilogues_and_helpers(gpu):
             assert relerr(ops.resize_bilinear(t, 2, hi, wi, ho, wo, relu=True), F.relu(ref)) < (1e-6 if dt == torch.float32 else 1e-2)
 
 
+def test_activation_epilogues_in_every_igemm_configuration(gpu):
+    """GELU / ReLU through EVERY bf16 tile configuration forced in turn (the ping-pong tiles apply them in their plain epilogue when there
+    is no residual, everything else in the generic kernel / the split-K reduce), ragged M, shapes of the DINOv2 MLP and of the DPT head"""
+    from freefine_amd import _lib as L
+    from freefine_amd import ops
+    import torch.nn.functional as F
+    lib = L.load()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(9)
+    try:
+        for cfg in range(lib.ffn_igemm_num_configs()):
+            lib.ffn_igemm_force_config(cfg)
+            for (M, N, K) in ((2740 + 8, 1024, 256), (5480, 640, 320)):
+                x = torch.randn(M, K, generator=g).to(dt).to(gpu)
+                wp = ops.pack_linear((torch.randn(N, K, generator=g) * K ** -0.5).to(gpu), dt)
+                b = torch.randn(N, generator=g).to(gpu)
+                r = torch.randn(M, N, generator=g).to(dt).to(gpu)
+                ref = x.double() @ wp.double()[:, :K].t() + b.double()
+                big = torch.full((M + 300, N), 7.0, dtype=dt, device=gpu)
+                assert relerr(ops.linear(x, wp, b, K=K, gelu=True, out=big[:M]), F.gelu(ref)) < 2e-2, (cfg, M, N, K, "gelu")
+                assert (big[M:] == 7.0).all(), (cfg, "rows past M written")
+                assert relerr(ops.linear(x, wp, b, K=K, relu=True), F.relu(ref)) < 2e-2, (cfg, M, N, K, "relu")
+                assert relerr(ops.linear(x, wp, b, K=K, relu=True, residual=r), F.relu(ref) + r.double()) < 2e-2, (cfg, M, N, K, "relu+res")
+            B, H, W, Cin, Cout = 2, 32, 40, 64, 256
+            xc = torch.randn(B, H * W, Cin, generator=g).to(dt).to(gpu)
+            wc = (torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).to(gpu)
+            bc = torch.randn(Cout, generator=g).to(gpu)
+            refc = F.relu(F.conv2d(xc.double().view(B, H, W, Cin).permute(0, 3, 1, 2), wc.to(dt).double(), bc.double(), padding=1))
+            refc = refc.permute(0, 2, 3, 1).reshape(B, H * W, Cout)
+            for sk in (0, 3):
+                assert relerr(ops.conv3x3(xc, ops.pack_conv3x3(wc, dt), bc, B, H, W, Cin, relu=True, splitk=sk), refc) < 2e-2, (cfg, "conv relu", sk)
+    finally:
+        lib.ffn_igemm_force_config(-1)
+
+
 @pytest.mark.parametrize("name,img_size,sizes", [("tiny", 70, ((70, 70), (56, 98))), ("mini", 518, ((42, 70),))])
 def test_depth_network_vs_oracle_and_reference_golden(gpu, name, img_size, sizes):
     """HipDepthAnything vs oracle/dpt.py AND vs the reference's own outputs (G8): ViT features of the last block and the depth map;
