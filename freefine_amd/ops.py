@@ -357,11 +357,18 @@ class AttnEntrySpec:
         return AttnEntrySpec(row_map[self.q_row], row_map[self.kv_row], self.w_const, self.w_slope, self.wq, self.kmask, self.qsel,
                              self.flags, logical_row if self.hr_row is None else self.hr_row)
 
-    def renumber(self, ren):
-        """the same term inside a launch that holds only a SUBSET of the physical rows (`ren`: physical row -> row of that launch)"""
-        if self.q_row not in ren or self.kv_row not in ren:
-            raise ValueError(f"attention term (q row {self.q_row}, kv row {self.kv_row}) reaches outside the rows of this phase {sorted(ren)}")
-        return AttnEntrySpec(ren[self.q_row], ren[self.kv_row], self.w_const, self.w_slope, self.wq, self.kmask, self.qsel, self.flags, self.hr_row)
+    def pinned(self, logical_row):
+        """the same term with the tiled-head rule pinned to `logical_row` (unless it already is pinned)"""
+        return self if self.hr_row is not None else AttnEntrySpec(self.q_row, self.kv_row, self.w_const, self.w_slope, self.wq, self.kmask, self.qsel,
+                                                                  self.flags, logical_row)
+
+    def renumber(self, ren, kv_ren=None):
+        """the same term inside a launch that holds only a SUBSET of the physical rows (`ren`: physical row -> row of that launch;
+        `kv_ren`: the same for the K / V row where the launch's K / V tensors are not row-aligned with its Q tensor)"""
+        kv_ren = ren if kv_ren is None else kv_ren
+        if self.q_row not in ren or self.kv_row not in kv_ren:
+            raise ValueError(f"attention term (q row {self.q_row}, kv row {self.kv_row}) reaches outside the rows of this phase {sorted(ren)} / {sorted(kv_ren)}")
+        return AttnEntrySpec(ren[self.q_row], kv_ren[self.kv_row], self.w_const, self.w_slope, self.wq, self.kmask, self.qsel, self.flags, self.hr_row)
 
     def shifted(self, base, logical_row, kv_base=None):
         """the same term inside an image-batched launch: this image's physical rows start at `base` (its K / V rows at `kv_base`

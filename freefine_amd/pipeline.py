@@ -290,9 +290,10 @@ class FreeFinePipeline:
         return min(idx) if idx else None
 
     def invert(self, image, prompt, num_inference_steps=50, num_actual_inference_steps=None, guidance_scale=7.5, eta=0.0,
-               return_intermediates=False, verbose=False, record_rows=None, **kwds):
+               return_intermediates=False, verbose=False, record_rows=None, record_kv=False, **kwds):
         """model.py:816-925 (HOT LOOP 1).  record_rows (reference-stream reuse): batch rows whose state at the UNet's join point
-        is recorded at every step for the guided loop that follows (self._ref_cache)."""
+        is recorded at every step for the guided loop that follows (self._ref_cache); record_kv: record their self-attention K / V
+        from the first modulated block on instead (hooks that leave the reference rows unmodulated: composition)."""
         batch_size = image.shape[0]
         if isinstance(prompt, list):
             if batch_size == 1:
@@ -309,14 +310,21 @@ class FreeFinePipeline:
         cache = None
         self._ref_cache = None
         if record_rows and self.reuse_ref_stream and not guidance_scale > 1. and hasattr(self.unet, "join_block"):
-            join, _ = self.unet.join_block(self._min_tca_block())
-            cache = dict(join=join, rows=list(record_rows), slots=[], latents=latents_list, text=text[list(record_rows)].clone(),
+            cache = dict(rows=list(record_rows), slots=[], latents=latents_list, text=text[list(record_rows)].clone(),
                          idx=torch.tensor(list(record_rows), device=self.device))
+            if record_kv:
+                mt = self._min_tca_block()
+                cache["kv_from"] = len(self.unet.transformers) if mt is None else int(mt)
+            else:
+                cache["join"] = self.unet.join_block(self._min_tca_block())[0]
         for i, t in enumerate(reversed(self.scheduler.timesteps)):
             if num_actual_inference_steps is not None and i >= num_actual_inference_steps:
                 continue
             model_inputs = torch.cat([latents] * 2) if guidance_scale > 1. else latents
-            if cache is not None:
+            if cache is not None and "kv_from" in cache:
+                noise_pred = self.unet(model_inputs, t, encoder_hidden_states=text, reuse=dict(mode="record", kv_from=cache["kv_from"]))
+                cache["slots"].append([(k.index_select(0, cache["idx"]), vt.index_select(0, cache["idx"])) for k, vt in self.unet.last_kv])
+            elif cache is not None:
                 noise_pred = self.unet(model_inputs, t, encoder_hidden_states=text, reuse=dict(mode="record", join=cache["join"]))
                 cache["slots"].append([s.index_select(0, cache["idx"]) for s in self.unet.last_boundary])
             else:
@@ -331,7 +339,7 @@ class FreeFinePipeline:
             return latents, latents_list
         return latents
 
-    def _take_ref_cache(self, refer_latents, n_act, text, ref_text_rows):
+    def _take_ref_cache(self, refer_latents, n_act, text, ref_text_rows, kv=False):
         """the recorded reference stream of the inversion that produced `refer_latents` (checked by identity: guided step k reads
         refer_latents[k + 1] = the input of inversion step n - k - 1, model.py:582 vs :883), or None where reuse does not apply:
         switched off, another inversion, style-align methods (they modulate every block), a modulated block before the join point,
@@ -339,17 +347,26 @@ class FreeFinePipeline:
         cache, self._ref_cache = self._ref_cache, None
         if cache is None or not self.reuse_ref_stream or len(cache["slots"]) != n_act or len(refer_latents) != n_act + 1:
             return None
+        if kv != ("kv_from" in cache):                        # (kv: the stored-K/V record of a hook whose reference rows stay unmodulated)
+            return None
         if any(refer_latents[k + 1] is not cache["latents"][n_act - k - 1] for k in range(n_act)):
             return None
         for c in (self.unet._ctrls() or []):
             if c.use_style_align:
                 return None
         mt = self._min_tca_block()
-        if mt is not None and mt < self.unet.join_block_tb(cache["join"]):
+        if mt is not None and mt < (cache["kv_from"] if kv else self.unet.join_block_tb(cache["join"])):
             return None
         if any(not torch.equal(text[r], cache["text"][i % cache["text"].shape[0]]) for i, r in enumerate(ref_text_rows)):
             return None
         return cache
+
+    @staticmethod
+    def _replay_kv_arg(cache, slot, R, P):
+        """HipUNet.forward's `reuse` argument of a composition step: latent rows per image [edit_u, ref_1 .. ref_R, edit_c], text rows per image
+        [""] * (1 + R) + the P prompts; the edit rows read text row 0 and the prompt rows"""
+        return dict(mode="replay_kv", kv_from=cache["kv_from"], ref=(False,) + (True,) * R + (False,), kv=slot,
+                    text_sel=[0] + list(range(1 + R, 1 + R + P)))
 
     def _cfg_row_map(self, text, n):
         """CFG batch rows are (latent i mod n, text row i).  Rows whose text embeddings coincide are the same UNet input, bit
@@ -521,6 +538,11 @@ class FreeFinePipeline:
         cfg_f = self._mask_f(cfg_masks_tensor) if local_edit_text else None
         noises = self._predraw_noise(num_inference_steps - start_step, (1,) + tuple(latents.shape[1:]), eta)
         var_mask = local_var_reg if local_perturbation else torch.ones_like(local_var_reg)
+        # stored reference K / V: the R reference rows (latent, timestep, "") are the very rows the inversion evaluated, and this hook never
+        # modulates them -- only the two edit rows run; the modulated blocks read the references' K / V from the inversion's record
+        n_act = num_inference_steps - start_step
+        R, P = refer_latents[0].shape[0] - 1, len(prompt)
+        cache = self._take_ref_cache(refer_latents, n_act, text, list(range(1, 1 + R)), kv=True) if batch_size == 1 + R and batch_size > 1 else None
         for i, t in enumerate(self.scheduler.timesteps):
             if i < start_step:
                 continue
@@ -533,7 +555,8 @@ class FreeFinePipeline:
                 self.controller.context_guidance = self.linear_param(i, start_step, end_step, num_inference_steps, end_scale=end_scale)
             elif method_type == "mmsa_es" and i >= end_step:
                 self.controller.use_tca = False
-            noise_pred = self.unet(torch.cat([latents, latents[0][None]]), t, encoder_hidden_states=text)
+            reuse = None if cache is None else self._replay_kv_arg(cache, cache["slots"][n_act - (i - start_step) - 1], R, P)
+            noise_pred = self.unet(torch.cat([latents, latents[0][None]]), t, encoder_hidden_states=text, reuse=reuse)
             eu, ec = noise_pred[0][None].contiguous(), noise_pred[-1][None].contiguous()
             noise_pred = ops.cfg_masked(eu, ec, cfg_f, guidance_scale)
             latents = self.ctrl_step(noise_pred, t, latents[0][None].contiguous(), var_mask, eta=eta,
@@ -671,8 +694,11 @@ class FreeFinePipeline:
     def DDIM_inversion_func_compose(self, img, compose_imgs, prompt, num_step, start_step=0, verbose=False):
         imgs = [img] + [self.resize_img(r, size=self._work_size(img)) for r in compose_imgs]
         source = torch.from_numpy(np.stack(imgs))
+        # rows 1 .. R = the reference images = the guided loop's reference rows: the composition hook leaves them unmodulated
+        # (attention.py:1284-1324), so their self-attention K / V are recorded for the loop (stored reference K / V)
         latents, latents_list = self.invert(source, prompt, guidance_scale=1.0, num_inference_steps=num_step,
-                                            num_actual_inference_steps=num_step - start_step, return_intermediates=True, verbose=verbose)
+                                            num_actual_inference_steps=num_step - start_step, return_intermediates=True, verbose=verbose,
+                                            record_rows=list(range(1, len(imgs))), record_kv=True)
         self.controller.reset()
         return latents_list
 
@@ -1027,7 +1053,8 @@ class FreeFinePipeline:
             for c in ctrls:
                 c.reset()
             _, inverted = self.invert(source, "", guidance_scale=1.0, num_inference_steps=num_step,
-                                      num_actual_inference_steps=num_step - start_step, return_intermediates=True)
+                                      num_actual_inference_steps=num_step - start_step, return_intermediates=True,
+                                      record_rows=[k * (1 + R) + r for k in range(K) for r in range(1, 1 + R)], record_kv=True)
             for c in ctrls:
                 c.reset()
             init, refer = inverted[-1], inverted[::-1]                     # [K (1 + R), 4, h, w]
@@ -1059,6 +1086,9 @@ class FreeFinePipeline:
             # latent rows of the UNet batch: per image [0 .. R, 0]
             row_idx = torch.tensor([i * (1 + R) + r for i in range(K) for r in list(range(1 + R)) + [0]], device=self.device)
             inter = [[init.view(K, 1 + R, *shape1)[k]] for k in range(K)] if return_intermediates else None
+            cache = self._take_ref_cache(refer, n_act, texts[0], list(range(1, 1 + R)), kv=True)
+            if cache is not None and any(not torch.equal(tx[r], cache["text"][0]) for tx in texts for r in range(1, 1 + R)):
+                cache = None
             for i, t in enumerate(self.scheduler.timesteps):
                 if i < start_step:
                     continue
@@ -1068,7 +1098,8 @@ class FreeFinePipeline:
                         c.context_guidance = self.linear_param(i, start_step, end_step, num_step, end_scale=end_scale)
                     elif method_type == "mmsa_es" and i >= end_step:
                         c.use_tca = False
-                eps = self.unet(latents.view(K * (1 + R), *shape1).index_select(0, row_idx), t, encoder_hidden_states=text_all)
+                reuse = None if cache is None else self._replay_kv_arg(cache, cache["slots"][n_act - (i - start_step) - 1], R, P)
+                eps = self.unet(latents.view(K * (1 + R), *shape1).index_select(0, row_idx), t, encoder_hidden_states=text_all, reuse=reuse)
                 eps = eps.view(K, R + 2, *shape1)
                 new = latents.clone()
                 for k in range(K):

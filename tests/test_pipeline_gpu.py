@@ -440,3 +440,43 @@ def test_image_batched_composition_matches_single(gpu, graph):
                 assert dev < 1e-4, (sel, i)
                 assert np.abs(imgs[j].astype(int) - single[i][0].astype(int)).max() <= 1
     assert traj_dev(model.last_intermediates[0], g[f"{name}_traj"]) < TOL
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_composition_stored_reference_kv_is_exact(gpu, graph):
+    """Composition hook (BASELINE configs[3] "shared K/V cache"): the R reference rows of the guided loop are the very (latent, timestep, "")
+    rows the inversion evaluated and the hook never modulates them, so the loop runs the two edit rows only and reads the references' K / V
+    of the modulated blocks from the inversion's record.  Against the plain recomputation (reuse off), against the REFERENCE's golden
+    trajectory, single and image-batched, both methods; `reuse_replays` proves the stored-K/V path ran at every guided step."""
+    g = np.load(os.path.join(GOLD, "g5_loops.npz"))
+    ori_img, coarse, img2 = synth_images()
+    oris, tgts = compose_masks()
+    n_guided = 10 - 6
+    as_np = lambda tr: [t.cpu().numpy() if t.ndim == 3 else t[0].cpu().numpy() for t in tr]
+    for name, kw in CMP_CASES:
+        trajs = {}
+        for reuse in (True, False):
+            model = make_pipe(gpu, "tiny", "compose", graph=graph)
+            model.reuse_ref_stream = reuse
+            model.FreeFine_cross_image_composition([ori_img, img2], oris, tgts, coarse, ["a cup", "a dog"], 7.5, 1.0, end_step=8, num_step=10,
+                                                   start_step=6, verbose=True, seed=11, dil_factor=9, end_scale=0.5, return_intermediates=True, **kw)
+            assert model.unet.reuse_replays == (n_guided if reuse else 0), (name, reuse, model.unet.reuse_replays)
+            trajs[reuse] = [t.clone() for t in model.last_intermediates]
+            dev = traj_dev(model.last_intermediates, g[f"{name}_traj"])
+            print(f"{name} graph={graph} stored K/V={reuse}: latent L-inf vs reference golden {dev:.2e}")
+            assert dev < TOL, (name, reuse)
+        assert traj_dev(trajs[True], as_np(trajs[False])) < 1e-4, name
+    name, kw = CMP_CASES[0]
+    common = dict(end_step=8, num_step=10, start_step=6, dil_factor=9, end_scale=0.5, **kw)
+    cases = [dict(img_lists=[ori_img, img2], ori_mask_lists=oris, tgt_mask_lists=tgts, coarse_input=coarse, guidance_text_list=["a cup", "a dog"]),
+             dict(img_lists=[img2, coarse], ori_mask_lists=oris[::-1], tgt_mask_lists=tgts[::-1], coarse_input=ori_img, guidance_text_list=["a tree", "grass"])]
+    outs = {}
+    for reuse in (True, False):
+        model = make_pipe(gpu, "tiny", "compose", graph=graph)
+        model.reuse_ref_stream = reuse
+        model.FreeFine_cross_image_composition_batch(cases, 7.5, 1.0, seeds=[11, 5], return_intermediates=True, **common)
+        assert model.unet.reuse_replays == (n_guided if reuse else 0)
+        outs[reuse] = [[t.clone() for t in tr] for tr in model.last_intermediates]
+    for j in range(2):
+        assert traj_dev(outs[True][j], as_np(outs[False][j])) < 1e-4, j
+    assert traj_dev(outs[True][0], g[f"{name}_traj"]) < TOL

@@ -138,3 +138,49 @@ def test_batched_composition_shifts_text_rows_by_the_text_block():
     assert [(e.q_row, e.kv_row) for e in last0] == [(3, 3), (3, 4), (3, 5)]
     assert [(e.q_row, e.kv_row) for e in last1] == [(7, 9), (7, 10), (7, 11)]
     assert (plan["passes"][0][5].q_row, plan["passes"][0][5].kv_row) == (5, 7)      # reference row 1 of image 1: latent row 5, text row 6 + 1
+
+
+def test_stored_kv_composition_tables():
+    """composition hook, stored reference K / V (replay_kv): K = 2 images, R = 2 references, P = 3 prompts.  The launch holds the two edit
+    rows of every image; the self attention of a recorded block reads the references' K / V from the rows BEHIND the 2 K computed ones
+    (image-major), the cross attention reads the 1 + P surviving text rows of its image."""
+    net = _net()
+    cs = []
+    for _ in range(2):
+        c = Attention_Modulator(start_layer=10)
+        c.num_att_layers = net.num_attention_calls
+        m = torch.zeros(128, 128, dtype=torch.uint8)
+        m[30:60, 30:60] = 1
+        c.src_masks, c.tgt_masks = torch.stack([m, m]), torch.stack([m, m, 1 - m])
+        c.use_tca, c.method, c.local_edit, c.context_guidance, c.layer_idx, c.prompt_length = True, "tca", True, 0.5, list(range(10, 16)), 3
+        cs.append(c)
+    net.set_attention_control("compose", cs)
+    net._row_map, net._enc_rows = None, 12
+    R, P, kv_from = 2, 3, 10
+    kv = [(torch.zeros(4, 1, 1), torch.zeros(4, 1, 1)) for _ in range(len(net.transformers) - kv_from)]
+    enc = torch.randn(12, 77, 64)
+    ru = net._prepare_reuse(dict(mode="replay_kv", kv_from=kv_from, ref=(False, True, True, False), kv=kv, text_sel=[0, 3, 4, 5]), 8, enc)
+    assert ru["sel"] == [0, 3] and ru["refs"] == [1, 2] and ru["idx_a"].tolist() == [0, 3, 4, 7] and len(ru["state"]) == 12
+    assert torch.equal(ru["enc_a"], enc[[0, 3, 4, 5, 6, 9, 10, 11]])
+    net._reuse = ru
+    for c in cs:
+        c.cur_att_layer = 1                                 # cross attention of block 0: edit_c blends the P prompts, per image
+    plan = net._plan(True, "down", 4, 256, 2)
+    assert len(plan["passes"]) == 3 and all(len(r) == 4 for r in plan["passes"])
+    assert [(e.q_row, e.kv_row) for e in plan["passes"][0]] == [(0, 0), (1, 1), (2, 4), (3, 5)]
+    assert [None if e is None else (e.q_row, e.kv_row) for e in plan["passes"][1]] == [None, (1, 2), None, (3, 6)]
+    assert [None if e is None else (e.q_row, e.kv_row) for e in plan["passes"][2]] == [None, (1, 3), None, (3, 7)]
+    for c in cs:
+        c.cur_att_layer = 20                                # self attention of block 10: K / V rows [e0_u, e0_c, e1_u, e1_c | r0_1, r0_2, r1_1, r1_2]
+    net._kv_ext = True
+    plan = net._plan(False, "up", 4, 256, 2)
+    net._kv_ext = False
+    assert [(e.q_row, e.kv_row) for e in plan["passes"][0]] == [(0, 0), (1, 1), (2, 2), (3, 3)]          # the edit rows' own K / V
+    assert [(e.q_row, e.kv_row) for e in plan["passes"][1]] == [(0, 4), (1, 4), (2, 6), (3, 6)]          # reference 1 of the own image
+    assert [(e.q_row, e.kv_row) for e in plan["passes"][2]] == [(0, 5), (1, 5), (2, 7), (3, 7)]          # reference 2
+    # the whole-forward fingerprint marks exactly the self-attention calls of blocks >= kv_from as extended
+    for c in cs:
+        c.cur_att_layer, c.cur_step = 0, 0
+    fp = net._plan_all_slow(8, 16, 16)[1]
+    ext = [i for i, f in enumerate(fp) if f != 0 and any(e is not None and e[1] >= 4 for r in f[2] for e in r) and i % 2 == 0]
+    assert ext == [2 * t for t in range(10, 16)]

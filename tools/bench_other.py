@@ -47,4 +47,15 @@ m2 = np.zeros((512, 512), np.uint8); m2[60:160, 300:420] = 255
 t2 = np.zeros((512, 512), np.uint8); t2[320:420, 280:400] = 255
 t = timed(lambda: model.FreeFine_cross_image_composition([ori_img, img2], [ori_mask * 255, m2], [tgt_mask, t2], coarse, ["a cup", "a dog"], 7.5, 1.0,
                                                          end_step=50, num_step=50, start_step=15, seed=3, dil_factor=15, end_scale=0.5, verbose=False))
-print(f"cross-image composition R=2 (N=50, S0=15, n=35): {t * 1e3:.0f} ms")
+compose = lambda: model.FreeFine_cross_image_composition([ori_img, img2], [ori_mask * 255, m2], [tgt_mask, t2], coarse, ["a cup", "a dog"], 7.5, 1.0,
+                                                         end_step=50, num_step=50, start_step=15, seed=3, dil_factor=15, end_scale=0.5, verbose=False)
+print(f"cross-image composition R=2 (N=50, S0=15, n=35), stored reference K/V ({model.unet.reuse_replays} replayed forwards so far): {t * 1e3:.0f} ms")
+model.reuse_ref_stream = False
+print(f"cross-image composition R=2, reference rows recomputed like the reference does: {timed(compose) * 1e3:.0f} ms")
+model.reuse_ref_stream = True
+ccases = [dict(img_lists=[ori_img, img2], ori_mask_lists=[ori_mask * 255, m2], tgt_mask_lists=[tgt_mask, t2], coarse_input=coarse, guidance_text_list=["a cup", "a dog"])] * 8
+for on in (True, False):
+    model.reuse_ref_stream = on
+    t = timed(lambda: model.FreeFine_cross_image_composition_batch(ccases, 7.5, 1.0, end_step=50, num_step=50, start_step=15, seeds=3, dil_factor=15,
+                                                                   end_scale=0.5, verbose=False), reps=1)
+    print(f"cross-image composition R=2, 8 images per batch, stored reference K/V {'on' if on else 'off'}: {t / 8 * 1e3:.0f} ms per image")
