@@ -61,6 +61,30 @@ __device__ __forceinline__ float att_max_groups(float x) {
     return att_max(__uint_as_float(c[0]), __uint_as_float(c[1]));
 }
 
+// Duplicate passes of a self-referencing row.  The TCA tables give EVERY row two passes -- (q = b, kv = ref(b), key mask under the
+// tiled-head rule, weight cg) and (q = b, kv = b, no mask, weight 1 - cg) -- and for a reference row ref(b) = b
+// (attention.py:1033-1035, 1060-1083).  Under the tiled-head rule the mask applies to the heads with even b * heads + head only
+// (attention.py:859 vs 761), so on the other heads that row's two passes are the same plain attention twice, blended with weights
+// that sum to one.  A (row, head) workgroup detects this and runs the first pass once with the summed weight: 1/12 of the two-pass
+// work of an edit batch (reference rows = 1/3, odd heads = 1/2, one pass of two).  Returns the pass to skip (folded into pass 0) or -1.
+__device__ __forceinline__ int att_duplicate_pass(const AttnParams& p, int b, int head) {
+    if (p.npass != 2) return -1;
+    const AttnEntry& a0 = p.e[b];
+    const AttnEntry& a1 = p.e[ATT_MAXB + b];
+    if ((a0.w_const == 0.f && a0.w_slope == 0.f) || (a1.w_const == 0.f && a1.w_slope == 0.f)) return -1;
+    if (a0.q_row != a1.q_row || a0.kv_row != a1.kv_row || a0.wq != a1.wq) return -1;
+    auto masked = [&](const AttnEntry& e) {
+        const int hb = e.hr_row > 0 ? e.hr_row - 1 : b;
+        return e.kmask && (!(e.flags & ATT_HEAD_RULE) || (((hb * p.heads + head) & 1) == 0));
+    };
+    return (masked(a0) || masked(a1)) ? -1 : 1;
+}
+__device__ __forceinline__ float att_pass_weight(const AttnParams& p, const AttnEntry& e) {
+    float w = e.w_const;
+    if (p.w_dev) w += e.w_slope * (*p.w_dev);
+    return w;
+}
+
 // KT = keys per tile, OCC = min waves per SIMD, MASKS = some entry of the launch carries a key mask (bf16: compiles the
 // mask-on-MFMA tile in; launches without masks -- cross attention, plain self attention -- get the leaner kernel)
 template <typename T, int DP, int QF, int KT = 64, int OCC = 1, bool MASKS = true>
@@ -117,6 +141,8 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
         const AttnEntry& e0 = p.e[pass * ATT_MAXB + b];
         nactive += (e0.w_const != 0.f || e0.w_slope != 0.f) ? 1 : 0;
     }
+    const int dup = att_duplicate_pass(p, b, head);      // a self-referencing row's second pass on a head the mask skips: folded into the first
+    if (dup >= 0) nactive = 1;
     T* __restrict__ Og = reinterpret_cast<T*>(p.out);
     if (nactive == 0) {   // nothing contributes to this output row: zeros
 #pragma unroll
@@ -137,8 +163,10 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
     for (int pass = 0; pass < p.npass; ++pass) {
         const AttnEntry& en = p.e[pass * ATT_MAXB + b];
         if (en.w_const == 0.f && en.w_slope == 0.f) continue;   // block-uniform skip
+        if (pass == dup) continue;
         float w = en.w_const;
         if (p.w_dev) w += en.w_slope * (*p.w_dev);
+        if (dup >= 0) w += att_pass_weight(p, p.e[dup * ATT_MAXB + b]);
         const int hb = en.hr_row > 0 ? en.hr_row - 1 : b;   // batch row the reference's j = b*heads + head refers to
         const bool pass_masked = en.kmask && (!(en.flags & ATT_HEAD_RULE) || (((hb * p.heads + head) & 1) == 0));  // block-uniform
 

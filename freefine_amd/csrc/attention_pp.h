@@ -70,6 +70,8 @@ __global__ __launch_bounds__(512) void attn_pp_kernel(const AttnParams p) {
         const AttnEntry& e0 = p.e[pass * ATT_MAXB + b];
         nactive += (e0.w_const != 0.f || e0.w_slope != 0.f) ? 1 : 0;
     }
+    const int dup = att_duplicate_pass(p, b, head);      // a self-referencing row's second pass on a head the mask skips: folded into the first
+    if (dup >= 0) nactive = 1;
     if (nactive == 0) {   // nothing contributes to this output row: zeros (workgroup-uniform: no barrier has been executed yet)
 #pragma unroll
         for (int f = 0; f < QF; ++f) {
@@ -106,8 +108,10 @@ __global__ __launch_bounds__(512) void attn_pp_kernel(const AttnParams p) {
     for (int pass = 0; pass < p.npass; ++pass) {
         const AttnEntry& en = p.e[pass * ATT_MAXB + b];
         if (en.w_const == 0.f && en.w_slope == 0.f) continue;   // workgroup-uniform skip
+        if (pass == dup) continue;
         float w = en.w_const;
         if (p.w_dev) w += en.w_slope * (*p.w_dev);
+        if (dup >= 0) w += att_pass_weight(p, p.e[dup * ATT_MAXB + b]);
         const int hb = en.hr_row > 0 ? en.hr_row - 1 : b;
         const bool pass_masked = MASKS && en.kmask && (!(en.flags & ATT_HEAD_RULE) || (((hb * p.heads + head) & 1) == 0));
 

@@ -57,6 +57,8 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const AttnParams p) {
         const AttnEntry& e0 = p.e[pass * ATT_MAXB + b];
         nactive += (e0.w_const != 0.f || e0.w_slope != 0.f) ? 1 : 0;
     }
+    const int dup = att_duplicate_pass(p, b, head);      // a self-referencing row's second pass on a head the mask skips: folded into the first
+    if (dup >= 0) nactive = 1;
     // output row q of batch row b, columns head * D + d .. + 3: fp32, or (out_pair) the bf16 pair form hi | lo at ldo / 2
     auto store_out = [&](int q, int d, const float* vv) {
         if (p.out_pair) store_pair_row4(reinterpret_cast<bf16*>(p.out) + ((long)b * p.S + q) * p.ldo + head * D + d, p.ldo / 2, vv);
@@ -82,8 +84,10 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const AttnParams p) {
     for (int pass = 0; pass < p.npass; ++pass) {
         const AttnEntry& en = p.e[pass * ATT_MAXB + b];
         if (en.w_const == 0.f && en.w_slope == 0.f) continue;
+        if (pass == dup) continue;
         float w = en.w_const;
         if (p.w_dev) w += en.w_slope * (*p.w_dev);
+        if (dup >= 0) w += att_pass_weight(p, p.e[dup * ATT_MAXB + b]);
         const int hb = en.hr_row > 0 ? en.hr_row - 1 : b;
         const bool pass_masked = MASKS && en.kmask && (!(en.flags & ATT_HEAD_RULE) || (((hb * p.heads + head) & 1) == 0));
 
