@@ -277,7 +277,8 @@ static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn, int splitk = 1) {
     long a_bytes;
     if (d.conv) {
         const int pix = d.x3 ? d.lda : d.Cin;                      // elements per input pixel
-        if (d.Cin % 64 != 0 || d.K != (d.x3 ? 27 : 9) * d.Cin) return false;
+        if (d.Cin % 64 != 0 || d.K != (d.conv == 2 ? 4 : (d.x3 ? 27 : 9)) * d.Cin) return false;
+        if (d.conv == 2 && (d.x3 || d.f8 || d.stride != 1 || d.upsample)) return false;
         if (d.x3 ? (d.Cin / 64 >= 100) : (d.Cin / 64 * 9 * (d.Cin / 64) >= 65536)) return false;      // exactness range of the tap reciprocal
         a_bytes = (long)(d.M / (d.Hout * d.Wout)) * d.Hin * d.Win * pix * 2;
         if (2 * d.Hin + 2 >= 32768 || 2 * d.Win + 2 >= 32768) return false;
@@ -477,6 +478,11 @@ static bool tune_enabled() {
 }
 // the deterministic rule-based choice (also what f32 parity mode uses): igemm_plan_for + igemm_exec_cfg mapped to a configuration
 static IgChoice heuristic_choice(const ffn_igemm_desc& d) {
+    if (d.conv == 2) {      // 2x2 sub-pixel convolutions exist in the ping-pong kernel only (ffn_igemm has checked that one of its tiles applies)
+        for (int bn : {320, 256})
+            for (int h : {256, 192})
+                if (d.N % bn == 0 && pp_ok(d, h, bn)) return IgChoice{bn == 320 ? (h == 256 ? CFG_PP_256x320 : CFG_PP_192x320) : (h == 256 ? CFG_PP_256x256 : CFG_PP_192x256), 1};
+    }
     // the ping-pong tile first, where its unsplit form applies and its tiles fill at least 3/4 of the chip: tile height = the one whose
     // tile count wastes the least of the last round of workgroups (the rule pp_trans_tile uses).  Without this, every launch that
     // cannot be tuned (FFN_IGEMM_TUNE=0, stream capture before a shape was seen, out aliasing residual) fell back to the 2-stage kernels
@@ -512,6 +518,7 @@ static int candidates_for(const ffn_igemm_desc& d, IgChoice* out, int cap) {
     for (int cfg = 0; cfg < CFG_COUNT; ++cfg) {
         const IgCfgInfo& c = kCfg[cfg];
         if ((d.x3 || d.f8) && !x3_cfg(cfg)) continue;
+        if (d.conv == 2 && !is_pp_cfg(cfg)) continue;
         if ((cfg == CFG_128x320 || cfg == CFG_128x160 || cfg == CFG_192x320) && (d.flags & FFN_IG_GEGLU)) continue;   // odd number of column blocks per wave
         if (is_halo_cfg(cfg)) {
             const int hb = halo_bytes_for(d, c.bm);
@@ -881,7 +888,17 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
     REQUIRE(d->rows_per_batch > 0, "igemm: rows_per_batch must be > 0");
     if (d->conv) {
         REQUIRE(d->Cin % epc == 0, "igemm: Cin=%d must be a multiple of %d", d->Cin, epc);
-        REQUIRE(d->K == 9 * d->Cin, "igemm: conv K=%d != 9*Cin=%d", d->K, 9 * d->Cin);
+        if (d->conv == 2) {
+            REQUIRE(dtype == FFN_BF16 && d->K == 4 * d->Cin && d->stride == 1 && d->upsample == 0 && d->pad >= 0 && d->pad <= 3 && d->splitk <= 1,
+                    "igemm: 2x2 convolution needs FFN_BF16, K = 4*Cin, stride 1, no upsample, pad in 0..3, no forced split");
+            bool any = false;
+            for (int bn : {320, 256})
+                for (int h : {256, 192}) any |= d->N % bn == 0 && pp_ok(*d, h, bn);
+            REQUIRE(any, "igemm: 2x2 convolution M=%d N=%d Cin=%d fits no ping-pong tile (Cin %% 64, N %% 256 / 320, M >= 192)", d->M, d->N, d->Cin);
+        } else {
+            REQUIRE(d->conv == 1, "igemm: conv=%d", d->conv);
+            REQUIRE(d->K == 9 * d->Cin, "igemm: conv K=%d != 9*Cin=%d", d->K, 9 * d->Cin);
+        }
         REQUIRE(d->stride == 1 || d->stride == 2, "igemm: stride %d", d->stride);
         REQUIRE(d->upsample == 0 || d->upsample == 1, "igemm: upsample %d", d->upsample);
         REQUIRE(d->M % (d->Hout * d->Wout) == 0, "igemm: M=%d not a multiple of Hout*Wout", d->M);

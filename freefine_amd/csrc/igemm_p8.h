@@ -189,8 +189,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
             const int c = (r * 21846) >> 16;
             ka = c * 128 + (r - 3 * c == 2 ? lo_bytes : 0);
             if (AMODE != AMODE_DENSE) {
-                tap_ky = (tap * 21846) >> 16;
-                tap_kx = tap - 3 * tap_ky;
+                tap_ky = p.conv == 2 ? (tap >> 1) : ((tap * 21846) >> 16);
+                tap_kx = tap - (p.conv == 2 ? 2 : 3) * tap_ky;
                 tap_off = (tap_ky * p.Win + tap_kx) * PIX;
             }
         } else if (AMODE == AMODE_DENSE) {
@@ -198,8 +198,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         } else {
             const int tap = (kt * cpt_rcp) >> 16;
             ka = (kt - tap * cpt) * 128;
-            tap_ky = (tap * 21846) >> 16;
-            tap_kx = tap - 3 * tap_ky;
+            tap_ky = p.conv == 2 ? (tap >> 1) : ((tap * 21846) >> 16);       // taps per window row: 2 (conv == 2) or 3
+            tap_kx = tap - (p.conv == 2 ? 2 : 3) * tap_ky;
             tap_off = (tap_ky * p.Win + tap_kx) * p.Cin * 2;
         }
     };
@@ -217,7 +217,9 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
                 const int ma = PP_ABL == 10 ? (m & 255) : m;       // 10: every tile reads the same 256 pixels (L2-hot A; results garbage)
                 const int b = ma / hw, rem = ma - b * hw;
                 const int yo = rem / p.Wout, xo = rem - yo * p.Wout;
-                const int y0 = yo * p.stride - p.pad, x0 = xo * p.stride - p.pad;       // in (nearest-2x upsampled) input coordinates
+                // conv == 2 (2x2 taps, one sub-pixel class of a 3x3 conv on a nearest-2x upsampled input): the window starts pad_y = pad >> 1
+                // rows above and pad_x = pad & 1 columns left of the output pixel
+                const int y0 = yo * p.stride - (p.conv == 2 ? (p.pad >> 1) : p.pad), x0 = xo * p.stride - (p.conv == 2 ? (p.pad & 1) : p.pad);       // in (nearest-2x upsampled) input coordinates
                 a_off[i] = ((b * p.Hin + (y0 >> p.upsample)) * p.Win + (x0 >> p.upsample)) * PIX + csrc * 16;
                 a_yx[i] = m < p.M ? ((y0 << 16) | (x0 & 0xffff)) : (int)0x80008000;       // rows past M: every tap out of the image
             }

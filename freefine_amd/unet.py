@@ -13,6 +13,7 @@ MI355X-first layout decisions
   * per-step scalars (timestep, context_guidance) live in device memory, so a whole forward can be captured in a hipGraph
     and replayed (capture=True) -- ~700 launches become one graph launch.
 """
+import os
 import weakref
 
 import torch
@@ -138,6 +139,11 @@ class HipUNet:
             blk.attn = [self._transformer(st, f"up_blocks.{i}.attentions.{j}", cfg.heads[n - 1 - i]) for j in range(cfg.layers_per_block + 1)] \
                 if rev_attn[i] else None
             blk.up = self._conv(st, f"up_blocks.{i}.upsamplers.0.conv") if i < n - 1 else None
+            blk.up2 = None                                  # the same convolution in its sub-pixel form (4/9 of the FLOPs), bf16 fast mode
+            if blk.up is not None and self.dtype == torch.bfloat16 and not self.x3 and os.environ.get("FFN_UP2X", "1") != "0":
+                wu = st[f"up_blocks.{i}.upsamplers.0.conv.weight"].to(self.device)
+                if ops.up2x_eligible(wu.shape[1], wu.shape[0], 192):
+                    blk.up2 = ops.pack_conv3x3_up2x(wu, self.dtype)
             self.up.append(blk)
         self.norm_out = (self._f32(st["conv_norm_out.weight"]), self._f32(st["conv_norm_out.bias"]))
         self.conv_out = self._conv(st, "conv_out")
@@ -751,7 +757,10 @@ class HipUNet:
                         B, temb_all = x.shape[0], temb_full[:x.shape[0]]
             if blk.up is not None:
                 C = x.shape[-1]
-                x = ops.conv3x3(x, blk.up[0], blk.up[1], B, H, W, C, upsample=True, out=cat_dst(C, 4 * H * W))
+                if blk.up2 is not None and ops.up2x_eligible(C, C, B * H * W):
+                    x = ops.conv3x3_up2x(x, blk.up2, blk.up[1], B, H, W, C, out=cat_dst(C, 4 * H * W))
+                else:
+                    x = ops.conv3x3(x, blk.up[0], blk.up[1], B, H, W, C, upsample=True, out=cat_dst(C, 4 * H * W))
                 H, W = 2 * H, 2 * W
         C = x.shape[-1]
         x = self._gn(x, self.norm_out, cfg.norm_eps, True)

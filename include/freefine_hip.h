@@ -66,7 +66,10 @@ typedef struct ffn_igemm_desc {
     int Hin, Win, Cin, Hout, Wout, stride, pad, upsample; /* conv only; upsample=1 fuses nearest-2x of the input */
     int flags;
     float alpha;
-    int conv; /* 0 = dense, 1 = 3x3 conv */
+    int conv; /* 0 = dense, 1 = 3x3 conv, 2 = 2x2 conv: taps (dy, dx) in {0,1}^2 read input pixel (yo - (pad >> 1) + dy, xo - (pad & 1) + dx),
+                 K = 4 Cin, stride 1 -- one sub-pixel class of a 3x3 conv behind a nearest-2x upsample (output pixel (2y+a, 2x+b) sees a 2x2
+                 window of the low-resolution input, pad = 2 (1 - a) + (1 - b), with the 3x3 taps that coincide summed: 4/9 of the FLOPs);
+                 bf16 ping-pong tiles only (Cin % 64 == 0, N % 256 or % 320 == 0, M >= 192) */
     int splitk;       /* 0 = let the library choose (needs ws), 1 = never split, k = force k K-slices */
     void* ws;         /* optional fp32 scratch for split-K partial slabs (>= splitk*M*N*4 bytes) or NULL */
     long ws_bytes;

@@ -989,6 +989,33 @@ def test_x3_attention_pingpong_schedule(gpu, S, Sk, heads):
         assert torch.equal(ops.attention(q, k, vt, heads, scale, [p0, p1], Sk=Sk, w_dev=cg, x3=True), out)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 8, 8, 1280, 1280), (5, 16, 16, 1280, 1280), (4, 32, 32, 640, 640), (2, 12, 20, 64, 256), (1, 16, 12, 128, 320)])
+def test_subpixel_upsample_conv(gpu, B, H, W, Cin, Cout):
+    """`nearest-2x upsample -> 3x3 conv` evaluated at low resolution as four 2x2 convolutions (conv = 2 of ffn_igemm: the ping-pong kernel
+    with two taps per window row and a per-class window origin) + pixel shuffle, at the three upsampler shapes of the SD UNet and two
+    ragged ones: against the fp64 convolution of the upsampled input with the bf16-rounded ORIGINAL weights (the summed taps are rounded
+    once, so the tolerance is bf16's), against the fused-gather kernel it replaces, written into a column view of a wider buffer."""
+    from freefine_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B + H + Cin)
+    dt = torch.bfloat16
+    x = rnd((B, H * W, Cin), dt, gpu, g)
+    w = rnd((Cout, Cin, 3, 3), torch.float32, gpu, g, (9 * Cin) ** -0.5)
+    b = rnd((Cout,), torch.float32, gpu, g)
+    assert ops.up2x_eligible(Cin, Cout, B * H * W)
+    w4 = ops.pack_conv3x3_up2x(w, dt)
+    big = torch.full((B, 4 * H * W, Cout + 64), 7.0, dtype=dt, device=gpu)
+    out = ops.conv3x3_up2x(x, w4, b, B, H, W, Cin, out=big[..., :Cout])
+    xr = F.interpolate(x.double().view(B, H, W, Cin).permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
+    ref = F.conv2d(xr, w.double(), b.double(), padding=1).permute(0, 2, 3, 1).reshape(B, 4 * H * W, Cout)
+    old = ops.conv3x3(x, ops.pack_conv3x3(w, dt), b, B, H, W, Cin, upsample=True)
+    e_new, e_old = relerr(out, ref), relerr(old, ref)
+    print(f"sub-pixel upsample conv {B}x{H}x{W} {Cin}->{Cout}: {e_new:.2e} (fused-gather 3x3 kernel: {e_old:.2e})")
+    assert e_new < tol(dt) and (big[..., Cout:] == 7.0).all()
+    for _ in range(2):
+        assert torch.equal(ops.conv3x3_up2x(x, w4, b, B, H, W, Cin), out.contiguous())
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # FFN_FP8: e4m3 operands for the 3x3 convolutions of the bf16 fast mode.  The GEMM is exact on its quantised operands up to fp32
 # accumulation and the bf16 output rounding, so the kernel tests quantise on the host and compare against the fp64 convolution of the
