@@ -277,8 +277,8 @@ static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn, int splitk = 1) {
     long a_bytes;
     if (d.conv) {
         const int pix = d.x3 ? d.lda : d.Cin;                      // elements per input pixel
-        if (d.Cin % 64 != 0 || d.K != (d.conv == 2 ? 4 : (d.x3 ? 27 : 9)) * d.Cin) return false;
-        if (d.conv == 2 && (d.x3 || d.f8 || d.stride != 1 || d.upsample)) return false;
+        if (d.Cin % 64 != 0 || d.K != (d.conv == 2 ? 4 : 9) * (d.x3 ? 3 : 1) * d.Cin) return false;
+        if (d.conv == 2 && (d.f8 || d.stride != 1 || d.upsample)) return false;
         if (d.x3 ? (d.Cin / 64 >= 100) : (d.Cin / 64 * 9 * (d.Cin / 64) >= 65536)) return false;      // exactness range of the tap reciprocal
         a_bytes = (long)(d.M / (d.Hout * d.Wout)) * d.Hin * d.Win * pix * 2;
         if (2 * d.Hin + 2 >= 32768 || 2 * d.Win + 2 >= 32768) return false;
@@ -889,11 +889,12 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
     if (d->conv) {
         REQUIRE(d->Cin % epc == 0, "igemm: Cin=%d must be a multiple of %d", d->Cin, epc);
         if (d->conv == 2) {
-            REQUIRE(dtype == FFN_BF16 && d->K == 4 * d->Cin && d->stride == 1 && d->upsample == 0 && d->pad >= 0 && d->pad <= 3 && d->splitk <= 1,
-                    "igemm: 2x2 convolution needs FFN_BF16, K = 4*Cin, stride 1, no upsample, pad in 0..3, no forced split");
+            REQUIRE((dtype == FFN_BF16 || dtype == FFN_BF16X3) && d->K == 4 * d->Cin && d->stride == 1 && d->upsample == 0 && d->pad >= 0 && d->pad <= 3 && d->splitk <= 1,
+                    "igemm: 2x2 convolution needs FFN_BF16 / FFN_BF16X3, K = 4*Cin, stride 1, no upsample, pad in 0..3, no forced split");
+            const ffn_igemm_desc v = dtype == FFN_BF16X3 ? x3_view(*d) : *d;
             bool any = false;
             for (int bn : {320, 256})
-                for (int h : {256, 192}) any |= d->N % bn == 0 && pp_ok(*d, h, bn);
+                for (int h : {256, 192}) any |= d->N % bn == 0 && pp_ok(v, h, bn);
             REQUIRE(any, "igemm: 2x2 convolution M=%d N=%d Cin=%d fits no ping-pong tile (Cin %% 64, N %% 256 / 320, M >= 192)", d->M, d->N, d->Cin);
         } else {
             REQUIRE(d->conv == 1, "igemm: conv=%d", d->conv);

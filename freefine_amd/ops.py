@@ -142,12 +142,13 @@ def up2x_eligible(cin, cout, rows):
     return cin % 64 == 0 and (cout % 256 == 0 or cout % 320 == 0) and rows >= 192
 
 
-def pack_conv3x3_up2x(w, dtype):
+def pack_conv3x3_up2x(w, dtype, x3=False):
     """[Cout, Cin, 3, 3] of a 3x3 conv that follows a nearest-2x upsample -> [4 Cout, 4 Cin] weights of its four sub-pixel classes.
     Output pixel (2y + a, 2x + b) sees the upsampled rows 2y + a - 1 .. 2y + a + 1 = low-resolution rows {y - 1, y, y} (a = 0) or {y, y, y + 1}
     (a = 1): a 2x2 window starting at (y + a - 1, x + b - 1) whose taps are sums of the 3x3 taps that coincide -- 4/9 of the multiplies.
-    Rows [c Cout, (c + 1) Cout) hold class c = 2a + b, k = (dy*2 + dx) Cin + ci.  The sums are taken in fp32 and rounded once."""
-    assert dtype == torch.bfloat16
+    Rows [c Cout, (c + 1) Cout) hold class c = 2a + b, k = (dy*2 + dx) Cin + ci.  The sums are taken in fp32 and rounded once.
+    x3 (split-bf16 mode, Cin % 64 == 0): the chunk-ordered [hi | lo | hi] form of pack_conv3x3 over the four taps."""
+    assert dtype == torch.bfloat16 or x3
     cout, cin = w.shape[:2]
     wf = w.float()
     groups = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}           # parity -> 3x3 tap indices feeding window position 0 / 1
@@ -161,24 +162,38 @@ def pack_conv3x3_up2x(w, dtype):
                         for kx in groups[b][dx]:
                             acc += wf[:, :, ky, kx]
                     out[2 * a + b, :, dy, dx] = acc
+    if x3:
+        assert cin % 64 == 0
+        hi, lo = split_hi_lo(out.reshape(4 * cout, 4, cin))
+        hc, lc = hi.reshape(4 * cout, 4, cin // 64, 64), lo.reshape(4 * cout, 4, cin // 64, 64)
+        return _mark_x3(torch.stack([hc, lc, hc], dim=3).reshape(4 * cout, 12 * cin).contiguous(), 2)
     return pack_linear(out.reshape(4 * cout, 4 * cin), dtype)
 
 
 def conv3x3_up2x(x, w4, bias, B, Hin, Win, Cin, *, out=None):
     """nearest-2x upsample followed by the 3x3 conv (pad 1) packed by pack_conv3x3_up2x, evaluated at LOW resolution: four 2x2 convolutions
     (conv = 2 of ffn_igemm, one per output-pixel parity class) into one [B, Hin*Win, 4 Cout] buffer + a pixel shuffle (layout plumbing).
-    x: [B, Hin*Win, Cin] bf16; returns [B, 4*Hin*Win, Cout] (written into `out`, which may be a column view of a wider buffer)."""
+    x: [B, Hin*Win, Cin] bf16 (split-bf16 weights: fp32, or its pair rows); returns [B, 4*Hin*Win, Cout] (written into `out`, which may be a
+    column view of a wider buffer)."""
     lib = L.load()
     cout = w4.shape[0] // 4
-    assert x.dtype == torch.bfloat16 and w4.shape[1] >= 4 * Cin and x.is_contiguous()
-    y = torch.empty(B, Hin * Win, 4 * cout, dtype=x.dtype, device=x.device)
+    x3 = is_x3(w4)
+    if x3:                                          # split-bf16 mode: fp32 activations as pair rows, fp32 result
+        xa = x if pair_width(x) is not None else split_pair(x, Cin)
+        assert pair_width(xa) == Cin
+        odt, dcode = torch.float32, L.FFN_BF16X3
+    else:
+        assert x.dtype == torch.bfloat16 and x.is_contiguous()
+        xa, odt, dcode = x, x.dtype, L.FFN_BF16
+    assert w4.shape[1] >= (12 if x3 else 4) * Cin
+    y = torch.empty(B, Hin * Win, 4 * cout, dtype=odt, device=x.device)
     for c in range(4):
         a, b = c >> 1, c & 1
         d = L.IgemmDesc()
-        d.A, d.W = x.data_ptr(), w4.data_ptr() + c * cout * w4.stride(0) * w4.element_size()
+        d.A, d.W = xa.data_ptr(), w4.data_ptr() + c * cout * w4.stride(0) * w4.element_size()
         d.bias, d.rowbias, d.residual = _p(bias), None, None
         d.M, d.N, d.K, d.Kpad = B * Hin * Win, cout, 4 * Cin, w4.stride(0)
-        d.lda, d.a_lo, d.x3 = Cin, 0, 0
+        d.lda, d.a_lo, d.x3 = (2 * Cin, Cin, 2) if x3 else (Cin, 0, 0)
         d.rows_per_batch, d.ldrb = Hin * Win, 0
         d.out, d.ldo, d.ldr = y.data_ptr() + c * cout * y.element_size(), 4 * cout, 0
         d.Hin, d.Win, d.Cin, d.Hout, d.Wout = Hin, Win, Cin, Hin, Win
@@ -186,12 +201,12 @@ def conv3x3_up2x(x, w4, bias, B, Hin, Win, Cin, *, out=None):
         d.flags, d.alpha, d.conv = 0, 1.0, 2
         d.splitk, d.ws, d.ws_bytes = 0, _workspace(x.device).data_ptr(), WS_BYTES
         if _PROF is None:
-            L.check(lib.ffn_igemm(_stream(), L.FFN_BF16, CT.byref(d)), "ffn_igemm(conv 2x2)")
+            L.check(lib.ffn_igemm(_stream(), dcode, CT.byref(d)), "ffn_igemm(conv 2x2)")
         else:
-            L.check(_timed(_igemm_name(lib, L.FFN_BF16, d), 2.0 * d.M * cout * 4 * Cin, 2 * (x.numel() + cout * 4 * Cin + d.M * cout),
-                           lambda: lib.ffn_igemm(_stream(), L.FFN_BF16, CT.byref(d))), "ffn_igemm(conv 2x2)")
+            L.check(_timed(_igemm_name(lib, dcode, d), 2.0 * d.M * cout * 4 * Cin, y.element_size() * (x.numel() + cout * 4 * Cin + d.M * cout),
+                           lambda: lib.ffn_igemm(_stream(), dcode, CT.byref(d))), "ffn_igemm(conv 2x2)")
     if out is None:
-        out = torch.empty(B, 4 * Hin * Win, cout, dtype=x.dtype, device=x.device)
+        out = torch.empty(B, 4 * Hin * Win, cout, dtype=odt, device=x.device)
     # pixel shuffle: class (a, b) of low-resolution pixel (y, x) is output pixel (2y + a, 2x + b)
     out.view(B, Hin, 2, Win, 2, cout).copy_(y.view(B, Hin, Win, 2, 2, cout).permute(0, 1, 3, 2, 4, 5))
     return out

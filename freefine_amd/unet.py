@@ -139,11 +139,11 @@ class HipUNet:
             blk.attn = [self._transformer(st, f"up_blocks.{i}.attentions.{j}", cfg.heads[n - 1 - i]) for j in range(cfg.layers_per_block + 1)] \
                 if rev_attn[i] else None
             blk.up = self._conv(st, f"up_blocks.{i}.upsamplers.0.conv") if i < n - 1 else None
-            blk.up2 = None                                  # the same convolution in its sub-pixel form (4/9 of the FLOPs), bf16 fast mode
-            if blk.up is not None and self.dtype == torch.bfloat16 and not self.x3 and os.environ.get("FFN_UP2X", "1") != "0":
+            blk.up2 = None                                  # the same convolution in its sub-pixel form (4/9 of the FLOPs): bf16 and split-bf16 modes
+            if blk.up is not None and (self.dtype == torch.bfloat16 or self.x3) and os.environ.get("FFN_UP2X", "1") != "0":
                 wu = st[f"up_blocks.{i}.upsamplers.0.conv.weight"].to(self.device)
                 if ops.up2x_eligible(wu.shape[1], wu.shape[0], 192):
-                    blk.up2 = ops.pack_conv3x3_up2x(wu, self.dtype)
+                    blk.up2 = ops.pack_conv3x3_up2x(wu, self.dtype, x3=self.x3)
             self.up.append(blk)
         self.norm_out = (self._f32(st["conv_norm_out.weight"]), self._f32(st["conv_norm_out.bias"]))
         self.conv_out = self._conv(st, "conv_out")

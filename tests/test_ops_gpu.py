@@ -1014,6 +1014,12 @@ def test_subpixel_upsample_conv(gpu, B, H, W, Cin, Cout):
     assert e_new < tol(dt) and (big[..., Cout:] == 7.0).all()
     for _ in range(2):
         assert torch.equal(ops.conv3x3_up2x(x, w4, b, B, H, W, Cin), out.contiguous())
+    # split-bf16 mode: fp32 activations, [hi | lo | hi] weights of the summed taps, fp32 result at fp32-level accuracy
+    xf = rnd((B, H * W, Cin), torch.float32, gpu, g)
+    o3 = ops.conv3x3_up2x(xf, ops.pack_conv3x3_up2x(w, torch.float32, x3=True), b, B, H, W, Cin)
+    xr = F.interpolate(xf.double().view(B, H, W, Cin).permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
+    ref3 = F.conv2d(xr, w.double(), b.double(), padding=1).permute(0, 2, 3, 1).reshape(B, 4 * H * W, Cout)
+    assert o3.dtype == torch.float32 and relerr(o3, ref3) < X3_TOL, relerr(o3, ref3)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
