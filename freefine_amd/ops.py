@@ -178,6 +178,17 @@ def conv3x3_up2x(x, w4, bias, B, Hin, Win, Cin, *, out=None):
     lib = L.load()
     cout = w4.shape[0] // 4
     x3 = is_x3(w4)
+    # the ping-pong kernel addresses its operands through 31-bit buffer resources: batches whose [B, HW, 4 Cout] result (or input) would pass
+    # 1 GiB go in slices of whole images (the VAE decoder at 256 x 256 x 512 channels)
+    per_img = Hin * Win * max(4 * cout * (4 if x3 else 2), Cin * (4 if x3 else 2))
+    nb = max(1, ((1 << 30) - 1) // per_img)
+    if B > nb:
+        if out is None:
+            out = torch.empty(B, 4 * Hin * Win, cout, dtype=torch.float32 if x3 else x.dtype, device=x.device)
+        for b0 in range(0, B, nb):
+            b1 = min(B, b0 + nb)
+            conv3x3_up2x(x[b0:b1], w4, bias, b1 - b0, Hin, Win, Cin, out=out[b0:b1])
+        return out
     if x3:                                          # split-bf16 mode: fp32 activations as pair rows, fp32 result
         xa = x if pair_width(x) is not None else split_pair(x, Cin)
         assert pair_width(xa) == Cin
