@@ -37,6 +37,9 @@ F_TCA = 72.5e9         # one extra attention pass in blocks 10-15 per sample-for
 F_VAE = 7.26e12        # 2 encodes + 2 decodes @512^2
 F_VAE_ENC, F_VAE_DEC = 1.117e12, 2.515e12
 F_UNET_PHASE_A = 0.4396e12   # conv_in + down blocks + mid block + up_blocks[0..1] of one sample-forward (FlopCounterMode on the oracle UNet)
+F_UP2X = 37.75e9        # what the sub-pixel form of the three up-sampling convolutions does not execute per sample-forward (5/9 of 67.95 GFLOP);
+F_UP2X_B = 16.78e9      # ... of a reference row in phase B (only up_blocks[2]'s upsampler); the VAE decoder's three: 386.5 GFLOP per decode
+F_VAE_UP2X = 386.5e9
 F_REF_TAIL = 57.8e9     # what a reference row runs behind the K / V projection of transformer block 15: both TCA passes of that block's self attention
                         # (2 x 21.5 GFLOP at S = 4096, C = 320) + to_out, cross attention, feed-forward, proj_out, conv_out (14.8 GFLOP)
 
@@ -408,7 +411,12 @@ def main():
         skipped = (rows_g - 2) * F_UNET_PHASE_A if reuse_on else 0.0
         if reuse_on and getattr(model, "drop_ref_tail", False):      # every guided step but the last: the reference rows stop after block 15's K / V
             skipped += (rows_g - 2) * F_REF_TAIL * (n - 1) / n
-        f_exec = n * ((2 + rows_g) * F_UNET - skipped + rows_g * F_TCA) + 2 * F_VAE_ENC + (1 if args.batch > 1 else 2) * F_VAE_DEC
+        n_dec = 1 if args.batch > 1 else 2
+        f_exec = n * ((2 + rows_g) * F_UNET - skipped + rows_g * F_TCA) + 2 * F_VAE_ENC + n_dec * F_VAE_DEC
+        up2x_on = args.dtype in ("bf16", "bf16x3") and os.environ.get("FFN_UP2X", "1") != "0"
+        if up2x_on:             # nearest-2x + 3x3 conv evaluated as four 2x2 convolutions at low resolution: 4/9 of those FLOPs
+            full_rows = 2 + (2 if reuse_on else rows_g)
+            f_exec -= n * (full_rows * F_UP2X + ((rows_g - 2) * F_UP2X_B if reuse_on else 0.0)) + n_dec * F_VAE_UP2X
         value = world * args.steps * args.concurrent * args.batch / dt
         line = {
             "metric": "edited images/sec/GPU @512px 50-step DDIM", "value": round(value, 4), "unit": "images/s", "n_gpus": world,
@@ -425,6 +433,7 @@ def main():
                        "reference_stream_reuse": ("on: the guided loop's reference row re-enters at up_blocks[2] from the state the inversion pass recorded for the "
                                                   "same (latent, timestep, prompt) and, at every step but the last, stops behind block 15's K / V projection (its eps is dead there); "
                                                   "outputs unchanged") if reuse_on else "off",
+                       "subpixel_upsample_convs": "on: nearest-2x + 3x3 conv = four 2x2 convolutions at low resolution (4/9 of the FLOPs), UNet and VAE decoder" if up2x_on else "off",
                        "vae_decode": "batched path decodes the edited latent only (the reference decodes the reference stream too and drops it unless return_ori)" if args.batch > 1 else "both streams, like the reference",
                        "algorithmic_tflop_per_image": round(f_img / 1e12, 1),
                        "whole_path_tflops_per_gpu": round(f_img * value / world / 1e12, 1),
