@@ -32,6 +32,59 @@ def depth_config(name="vitl"):
                            features=head[0], out_channels=head[1], interpolate_offset=0.1, ln_eps=1e-6)
 
 
+def depth_param_shapes(cfg):
+    """name -> shape of DPT_DINOv2(encoder, features, out_channels, use_bn=False, use_clstoken=False).state_dict() (dpt.py:143-153)"""
+    C, hid = cfg.embed_dim, cfg.embed_dim * cfg.mlp_ratio
+    n = (cfg.img_size // cfg.patch) ** 2
+    sh = {"pretrained.cls_token": (1, 1, C), "pretrained.pos_embed": (1, n + 1, C), "pretrained.mask_token": (1, C),
+          "pretrained.patch_embed.proj.weight": (C, 3, cfg.patch, cfg.patch), "pretrained.patch_embed.proj.bias": (C,),
+          "pretrained.norm.weight": (C,), "pretrained.norm.bias": (C,)}
+    for i in range(cfg.depth):
+        p = f"pretrained.blocks.{i}."
+        sh.update({p + "norm1.weight": (C,), p + "norm1.bias": (C,), p + "attn.qkv.weight": (3 * C, C), p + "attn.qkv.bias": (3 * C,),
+                   p + "attn.proj.weight": (C, C), p + "attn.proj.bias": (C,), p + "ls1.gamma": (C,),
+                   p + "norm2.weight": (C,), p + "norm2.bias": (C,), p + "mlp.fc1.weight": (hid, C), p + "mlp.fc1.bias": (hid,),
+                   p + "mlp.fc2.weight": (C, hid), p + "mlp.fc2.bias": (C,), p + "ls2.gamma": (C,)})
+    oc, f = cfg.out_channels, cfg.features
+    h = "depth_head."
+    for i in range(4):
+        sh[h + f"projects.{i}.weight"], sh[h + f"projects.{i}.bias"] = (oc[i], C, 1, 1), (oc[i],)
+        sh[h + f"scratch.layer{i + 1}_rn.weight"] = (f, oc[i], 3, 3)
+    sh[h + "resize_layers.0.weight"], sh[h + "resize_layers.0.bias"] = (oc[0], oc[0], 4, 4), (oc[0],)
+    sh[h + "resize_layers.1.weight"], sh[h + "resize_layers.1.bias"] = (oc[1], oc[1], 2, 2), (oc[1],)
+    sh[h + "resize_layers.3.weight"], sh[h + "resize_layers.3.bias"] = (oc[3], oc[3], 3, 3), (oc[3],)
+    for i in range(1, 5):
+        r = h + f"scratch.refinenet{i}."
+        sh[r + "out_conv.weight"], sh[r + "out_conv.bias"] = (f, f, 1, 1), (f,)
+        for u in ("resConfUnit1", "resConfUnit2"):
+            for c in ("conv1", "conv2"):
+                sh[r + f"{u}.{c}.weight"], sh[r + f"{u}.{c}.bias"] = (f, f, 3, 3), (f,)
+    sh[h + "scratch.output_conv1.weight"], sh[h + "scratch.output_conv1.bias"] = (f // 2, f, 3, 3), (f // 2,)
+    sh[h + "scratch.output_conv2.0.weight"], sh[h + "scratch.output_conv2.0.bias"] = (32, f // 2, 3, 3), (32,)
+    sh[h + "scratch.output_conv2.2.weight"], sh[h + "scratch.output_conv2.2.bias"] = (1, 32, 1, 1), (1,)
+    return sh
+
+
+def synthetic_state(cfg, seed=0):
+    """seeded random weights of a plausible scale for benchmarks without a checkpoint (`tools/bench_depth.py`; there is no network)"""
+    g = torch.Generator().manual_seed(seed)
+    st = {}
+    for k, shp in depth_param_shapes(cfg).items():
+        if k.endswith("norm.weight") or k.endswith("norm1.weight") or k.endswith("norm2.weight"):
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith(".gamma"):
+            t = 0.5 + 0.25 * torch.rand(shp, generator=g)
+        elif k.endswith(".bias"):
+            t = 0.05 * torch.randn(shp, generator=g)
+        elif k.endswith("pos_embed") or k.endswith("cls_token") or k.endswith("mask_token"):
+            t = 0.2 * torch.randn(shp, generator=g)
+        else:
+            fan_in = shp[0] if ("resize_layers.0" in k or "resize_layers.1" in k) else math.prod(shp[1:])
+            t = torch.randn(shp, generator=g) / math.sqrt(fan_in)
+        st[k] = t.float()
+    return st
+
+
 class _O:
     pass
 

@@ -47,11 +47,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", default="", help="write the per-kernel event table (HIP events around every launch of one forward) to this file")
     a = ap.parse_args()
-    from freefine_amd.depth import HipDepthAnything, depth_config
-    from oracle import dpt as OD                      # (weights generator + the CPU baseline; not on the timed GPU path)
+    from freefine_amd.depth import HipDepthAnything, depth_config, synthetic_state
     dev = torch.device("cuda:0")
     cfg = depth_config(a.encoder)
-    st = OD.dpt_synthetic_state(OD.dpt_config(a.encoder), seed=1)
+    st = synthetic_state(cfg, seed=1)
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     net = HipDepthAnything(cfg, st, dtype=dt, device=dev)
     x = torch.randn(a.batch, 3, a.size, a.size, generator=torch.Generator().manual_seed(0)).to(dev)
@@ -80,6 +79,7 @@ def main():
                 ms = max(v["total_ms"], 1e-9)
                 f.write(f"{k}\t{v['calls']}\t{v['total_ms']:.3f}\t{v['flops'] / ms / 1e9:.1f}\t{v['bytes'] / ms / 1e6:.1f}\n")
     if not a.no_cpu_baseline:
+        from oracle import dpt as OD                  # the CPU baseline leg only: the oracle is never on the GPU path
         torch.set_num_threads(max(8, min(32, torch.get_num_threads())))
         xc = x[:1].cpu()
         t0 = time.time()
