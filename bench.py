@@ -13,7 +13,18 @@ as it is for the reference).
 Rank r edits its own images (weak scaling: independent units, no data-path collective); value = images of
 all ranks / max-over-ranks time.
 
+The HEADLINE mode is `--dtype bf16x3` (split-bf16: fp32 storage, every GEMM / attention product on three bf16 MFMAs per term): the fastest
+mode that holds the north star's 1e-3 latent tolerance on the metric's own schedules -- tests/test_pipeline_gpu.py gates it (and the f32 mode)
+at 1e-3 ABSOLUTE against reference-generated N = 50 trajectories (G9: start_step 0 / 35 / 15 / 1) and against full-size SD-2.1 oracle
+trajectories at N = 50 (G10: start_step 35 and 0).  The bf16 mode (4.4 images/s in round 3) does NOT hold that tolerance and is reported under
+`fast_modes`, never as `value`.  Weights: seeded default-init tensors + freefine_amd.weights.plant_denoiser_path, so that the 50-step
+trajectory is a denoising one with O(1) latents (with purely random weights nothing removes the DDPM noise and |latent| grows 14.6x).
+The text encoder inside the timed region is a real-size CLIP-shaped transformers model on the device with the prompt cache OFF.
+
 Extra objects on the JSON line:
+  parity        this run's own check: the headline mode's latent trajectory against the f32 mode's over the FULL schedule (absolute L-inf,
+                `passes`), beside the names of the gates that pin both modes to the reference / oracle.
+  fast_modes    bf16 (and with --fp8-leg the e4m3-convolution variant): throughput by the same protocol + the deviation that disqualifies it.
   roofline      the dominant kernel (largest total time of an eagerly executed, HIP-event-timed image in this very process):
                 achieved = algorithmic FLOPs per launch / average launch duration; peak = dense MFMA peak of the dtype.
   cpu_baseline  the CPU oracle (oracle/, "port") timed on this host's cores on a bounded sample of the same workload.
@@ -72,21 +83,33 @@ def build_model(args, device, rank, world):
     from freefine_amd.config import UNetConfig, VAEConfig
     from freefine_amd.pipeline import FreeFinePipeline
     from freefine_amd.scheduler import DDIMScheduler
-    from freefine_amd.text import ByteTokenizer, SyntheticTextEncoder
-    from freefine_amd.weights import synthetic_state, unet_param_shapes, vae_param_shapes
+    from freefine_amd.text import ByteTokenizer, SyntheticTextEncoder, clip_shaped_text_encoder
+    from freefine_amd.weights import plant_denoiser_path, synthetic_state, unet_param_shapes, vae_param_shapes
     ucfg, vcfg = UNetConfig.preset(args.model), VAEConfig.preset(args.vae)
+
+    def unet_state():       # seeded default-init tensors + the planted denoiser path (O(1) latents over the 50-step schedule, see weights.py)
+        st = synthetic_state(unet_param_shapes(ucfg), 0)
+        return plant_denoiser_path(st, ucfg, args.planted) if args.planted > 0 else st
     if world > 1:
         from freefine_amd import dist as FD
         # rank 0 generates (stands for: reads) the weights, the others receive them over RCCL straight into device memory; bf16 payload
         # for the matrices in fast mode (the packers round them to bf16 anyway: packed weights are bit-identical on every rank)
         mdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-        ust = FD.broadcast_state(synthetic_state(unet_param_shapes(ucfg), 0) if rank == 0 else None, unet_param_shapes(ucfg), device, matrix_dtype=mdt)
+        ust = FD.broadcast_state(unet_state() if rank == 0 else None, unet_param_shapes(ucfg), device, matrix_dtype=mdt)
         vst = FD.broadcast_state(synthetic_state(vae_param_shapes(vcfg), 1) if rank == 0 else None, vae_param_shapes(vcfg), device, matrix_dtype=mdt)
     else:
-        ust, vst = synthetic_state(unet_param_shapes(ucfg), 0), synthetic_state(vae_param_shapes(vcfg), 1)
+        ust, vst = unet_state(), synthetic_state(vae_param_shapes(vcfg), 1)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model = FreeFinePipeline.from_state(ucfg, ust, vcfg, vst, ByteTokenizer(), SyntheticTextEncoder(ucfg.cross_attention_dim), None, dtype, device,
+    global _TEXT_ENCODER
+    if args.text == "clip":
+        if _TEXT_ENCODER is None:       # seeded: identical on every rank; shared by every mode built in this process
+            _TEXT_ENCODER = clip_shaped_text_encoder(ucfg.cross_attention_dim).to(device)
+        enc = _TEXT_ENCODER
+    else:
+        enc = SyntheticTextEncoder(ucfg.cross_attention_dim)
+    model = FreeFinePipeline.from_state(ucfg, ust, vcfg, vst, ByteTokenizer(), enc, None, dtype, device,
                                         x3=args.dtype == "bf16x3", fp8_conv=bool(getattr(args, "fp8_conv", False)) and args.dtype == "bf16")
+    model.text_cache = False            # every edit pays the text encoder inside the timed region (2 encoder calls per image)
     model.scheduler = DDIMScheduler.from_config(model.scheduler.config)
     controller = Attention_Modulator(start_layer=10)
     model.controller = controller
@@ -160,100 +183,100 @@ def roofline_leg(model, args):
     return out, table
 
 
-def parity_leg(args, device, model_fast):
-    """The mode the <= 1e-3 latent parity claim is made in, measured in this very run beside the headline:
-      (1) throughput of each parity mode (same path, same weights, `--parity-batch` edits per UNet batch on one stream, HIP graphs):
-          f32 (exact-fp32 MFMA chain; verified against the oracle by tests/test_pipeline_gpu.py, incl. the full-size loop test) and,
-          when built, bf16x3 (split-bf16 operands, fp32 storage);
-      (2) the headline mode's latent deviation from f32 over the FULL schedule of the workload (one image, same seed / noise)."""
+def one_image_trajectory(model, args):
+    """the latent trajectory of ONE edit of the workload (image 0, seed 42) over the full schedule: [n + 1, 2, 4, 64, 64] on the host"""
+    ori_img, ori_mask, coarse, tgt_mask, draw = synth_inputs(0)
+    model.FreeFine_generation(ori_img, ori_mask, coarse, tgt_mask, "a photo of a cup", 7.5, 1.0, end_step=args.num_step, num_step=args.num_step,
+                              start_step=args.start_step, method_type="tca", verbose=False, seed=42, draw_mask=draw, end_scale=0.0,
+                              return_intermediates=True)
+    return torch.stack([t.float() for t in model.last_intermediates]).cpu()
+
+
+def deviation(traj, ref):
+    d = (traj - ref).abs().flatten(1).max(dim=1).values
+    amax = ref.abs().max().item()
+    return {"max_over_steps": float(f"{d.max().item():.3e}"), "final": float(f"{d[-1].item():.3e}"), "worst_step": int(d.argmax()),
+            "relative_to_latent_abs_max": float(f"{d.max().item() / amax:.3e}")}
+
+
+def timed_mode(args, device, mode, steps, fp8=False, base=7000):
+    """throughput of another arithmetic mode by the headline's protocol: same images per UNet batch, same number of HIP streams, one warm-up
+    pass per stream (tuning, graph capture), then `steps` timed steps between synchronisations.  Returns (record, model)."""
     import copy
-    out = {"tolerance_latent_linf": 1e-3, "modes": {}}
-    ref_traj = None
-    global _F32_TRAJ
-    for mode in args.parity_modes.split(","):
-        a = copy.copy(args)
-        a.dtype, a.batch = mode, args.parity_batch
-        try:
-            m = build_model(a, device, 0, 1)
-        except (ValueError, NotImplementedError) as e:
-            out["modes"][mode] = {"error": str(e)}
-            continue
-        ori_img, ori_mask, coarse, tgt_mask, draw = synth_inputs(0)
-        kw = dict(end_step=args.num_step, num_step=args.num_step, start_step=args.start_step, method_type="tca", verbose=False, seed=42,
-                  draw_mask=draw, end_scale=0.0, return_intermediates=True)
-        m.FreeFine_generation(ori_img, ori_mask, coarse, tgt_mask, "a photo of a cup", 7.5, 1.0, **kw)
-        traj = torch.stack([t.float() for t in m.last_intermediates]).cpu()
-        if ref_traj is None:
-            ref_traj = traj        # the first mode listed (f32) is the reference of the deviation figures
-            _F32_TRAJ = traj
-            model_fast.FreeFine_generation(ori_img, ori_mask, coarse, tgt_mask, "a photo of a cup", 7.5, 1.0, **kw)
-            ft = torch.stack([t.float() for t in model_fast.last_intermediates]).cpu()
-            d = (ft - ref_traj).abs().flatten(1).max(dim=1).values
-            amax = ref_traj.abs().max().item()
-            out["latent_abs_max"] = round(amax, 3)
-            out["note"] = ("deviations are ABSOLUTE latent L-inf between two modes of this engine over the full schedule on seeded RANDOM weights, whose "
-                           "trajectory is not a denoising one (|latent| grows to latent_abs_max): divide by latent_abs_max for the relative figure; against "
-                           "the oracle on O(1) latents the gates are tests/test_pipeline_gpu.py (f32 <= 2e-5, bf16x3 <= 5e-4, tolerance 1e-3)")
-            out[f"{args.dtype}_vs_{mode}_latent_linf"] = {"final": round(d[-1].item(), 5), "max_over_steps": round(d.max().item(), 5),
-                                                         "relative_to_latent_abs_max": float(f"{d.max().item() / amax:.3e}"),
-                                                         "schedule": f"N={args.num_step}, start_step={args.start_step}, one image, seed 42",
-                                                         "latent_abs_max": round(amax, 3)}
-            dev = None
-        else:
-            d = (traj - ref_traj).abs().flatten(1).max(dim=1).values
-            dev = {"final": round(d[-1].item(), 6), "max_over_steps": round(d.max().item(), 6),
-                   "relative_to_latent_abs_max": float(f"{d.max().item() / ref_traj.abs().max().item():.3e}")}
-        for i in range(2):                                   # warm-up (tuning, graph capture), then the timed step
-            torch.cuda.synchronize()
-            t0 = time.time()
-            edit_once(m, a, 7000 + i)
-            torch.cuda.synchronize()
-            dt = time.time() - t0
-        v = args.parity_batch / dt
-        n = args.num_step - args.start_step
-        f_img = n * (2 * F_UNET + 4 * F_UNET + 4 * F_TCA) + F_VAE
-        rec = {"value": round(v, 4), "unit": "images/s", "images_per_unet_batch": args.parity_batch, "concurrent_streams": 1, "steps": 1,
-               "whole_path_frac_of_mfma_peak": round(f_img * v / 1e12 / PEAK_TFLOPS[mode], 4), "mfma_peak_tflops": round(PEAK_TFLOPS[mode], 1)}
-        if dev is not None:
-            rec["latent_linf_vs_f32"] = dev
-        out["modes"][mode] = rec
-        del m
-        torch.cuda.empty_cache()
-    return out
-
-
-_F32_TRAJ = None
-
-
-def fp8_leg(args, device):
-    """the bf16 fast mode with e4m3 ResBlock convolutions (FFN_FP8; north star: "MFMA (bf16/fp8)"): REPORTED beside the headline, never as
-    parity -- throughput at the headline's batch on one stream (timed BEFORE the parity leg: its minute of fp32 / split-bf16 work leaves the
-    chip at a lower clock, which cost this figure 5-8 %).  Returns (record, model); fp8_deviation() adds the latent deviation afterwards."""
-    import copy
+    import threading
     a = copy.copy(args)
-    a.fp8_conv, a.dtype = True, "bf16"
+    a.dtype, a.fp8_conv = mode, fp8
     m = build_model(a, device, 0, 1)
-    rec = {"unit": "images/s", "images_per_unet_batch": args.batch, "concurrent_streams": 1, "steps": 1,
-           "what": "bf16 fast mode with the two 3x3 convolutions of every ResBlock on e4m3 operands (55 % of the UNet FLOPs; v_mfma_f32_16x16x32_fp8_fp8)"}
-    for i in range(2):
-        torch.cuda.synchronize()
-        t0 = time.time()
-        edit_once(m, a, 8000 + i)
-        torch.cuda.synchronize()
-        dt = time.time() - t0
-    rec["value"] = round(args.batch / dt, 4)
+    models = [m] + [add_sibling(m) for _ in range(args.concurrent - 1)]
+    streams = [torch.cuda.Stream(device=device) for _ in models]
+    for j, (mm, st) in enumerate(zip(models, streams)):
+        with torch.cuda.stream(st):
+            edit_once(mm, a, base + 10 * j)
+        st.synchronize()
+
+    def worker(j):
+        torch.cuda.set_device(device)
+        with torch.cuda.stream(streams[j]):
+            for i in range(steps):
+                edit_once(models[j], a, base + 100 + 10 * j + i)
+        streams[j].synchronize()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    th = [threading.Thread(target=worker, args=(j,)) for j in range(len(models))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    v = steps * len(models) * args.batch / dt
+    n = args.num_step - args.start_step
+    f_img = n * (2 * F_UNET + 4 * F_UNET + 4 * F_TCA) + F_VAE
+    rec = {"value": round(v, 4), "unit": "images/s", "steps": steps, "images_per_unet_batch": args.batch, "concurrent_streams": len(models),
+           "whole_path_frac_of_mfma_peak": round(f_img * v / 1e12 / PEAK_TFLOPS[mode], 4), "mfma_peak_tflops": round(PEAK_TFLOPS[mode], 1)}
+    del models[1:]
     return rec, m
 
 
-def fp8_deviation(args, rec, m):
-    """latent deviation of the fp8-conv mode from the f32 run of the parity leg (same schedule, same seed)"""
-    if _F32_TRAJ is not None:
-        ori_img, ori_mask, coarse, tgt_mask, draw = synth_inputs(0)
-        m.FreeFine_generation(ori_img, ori_mask, coarse, tgt_mask, "a photo of a cup", 7.5, 1.0, end_step=args.num_step, num_step=args.num_step,
-                              start_step=args.start_step, method_type="tca", verbose=False, seed=42, draw_mask=draw, end_scale=0.0, return_intermediates=True)
-        d = (torch.stack([t.float() for t in m.last_intermediates]).cpu() - _F32_TRAJ).abs().flatten(1).max(dim=1).values
-        rec["latent_linf_vs_f32"] = {"final": round(d[-1].item(), 5), "max_over_steps": round(d.max().item(), 5),
-                                     "relative_to_latent_abs_max": float(f"{d.max().item() / _F32_TRAJ.abs().max().item():.3e}")}
+def parity_leg(args, device, model):
+    """This run's own parity evidence for the HEADLINE mode: its latent trajectory over the FULL schedule of the workload (one image, same
+    seed and noise) against the f32 mode's (exact-fp32 MFMA chain, itself <= 2e-5 from the oracle on the full-size fixtures), ABSOLUTE L-inf
+    at every step, `passes` = max <= 1e-3; and the f32 mode's own throughput by the headline's protocol."""
+    global _F32_TRAJ
+    out = {"tolerance_latent_linf": 1e-3,
+           "gates": ("tests/test_pipeline_gpu.py::test_metric_schedules_n50_vs_reference_golden (tiny topology, N=50, start_step 0/35/15, bg-gen 1, "
+                     "compose 15: reference-generated, f32 + bf16x3) and ::test_full_size_n50_schedules_vs_oracle_fixture (SD-2.1 topology 64x64, N=50, "
+                     "start_step 35 and 0: oracle-generated, f32 + bf16x3), absolute latent L-inf <= 1e-3 at every step")}
+    rec, m32 = timed_mode(args, device, "f32", args.extra_steps)
+    _F32_TRAJ = ref = one_image_trajectory(m32, args)
+    del m32
+    torch.cuda.empty_cache()
+    out["latent_abs_max"] = round(ref.abs().max().item(), 3)
+    out["latent_std_start_end"] = [round(ref[0, 0].std().item(), 3), round(ref[-1, 0].std().item(), 3)]
+    out["schedule"] = f"N={args.num_step}, start_step={args.start_step}, one image, seed 42, planted denoiser gain {args.planted}"
+    if args.dtype != "f32":
+        dev = deviation(one_image_trajectory(model, args), ref)
+        dev["passes"] = bool(dev["max_over_steps"] <= 1e-3)
+        out[f"{args.dtype}_vs_f32_latent_linf"] = dev
+        out["headline_passes_tolerance"] = dev["passes"]
+    out["f32_mode"] = rec
+    return out
+
+
+def fast_modes_leg(args, device):
+    """the modes that do NOT hold the tolerance, by the headline's protocol, each with the deviation that disqualifies it"""
+    out = {}
+    modes = [("bf16", False)] + ([("bf16+fp8_conv", True)] if args.fp8_leg else [])
+    for name, fp8 in modes:
+        rec, m = timed_mode(args, device, "bf16", args.extra_steps, fp8=fp8, base=8000)
+        if _F32_TRAJ is not None:
+            dev = deviation(one_image_trajectory(m, args), _F32_TRAJ)
+            dev["passes"] = bool(dev["max_over_steps"] <= 1e-3)
+            rec["latent_linf_vs_f32"] = dev
+        rec["what"] = ("bf16 storage and MFMA operands, fp32 accumulate / softmax / statistics" +
+                       ("; the two 3x3 convolutions of every ResBlock on e4m3 operands (v_mfma_f32_16x16x32_fp8_fp8)" if fp8 else ""))
+        out[name] = rec
+        del m
+        torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline_leg(args):
@@ -290,7 +313,7 @@ def cpu_baseline_leg(args):
             t_vae = 2 * (time.time() - t0)     # two images are encoded and decoded per edit
     n = args.num_step - args.start_step
     per_image = n * (t_inv + t_den) + t_vae
-    return dict(value=round(1.0 / per_image, 6), unit="images/s", cores=cores, kind="port",
+    return dict(value=round(1.0 / per_image, 6), unit="images/s", cores=cores, host_cpu_count=os.cpu_count(), kind="port",
                 sample=f"1 inversion UNet forward B=2 ({t_inv:.2f}s) + 1 guided forward B=4 with TCA ({t_den:.2f}s) at 64x64, x{n} steps; "
                        f"VAE encode+decode @512^2 once x2 ({t_vae:.2f}s); torch fp32, {cores} threads")
 
@@ -302,7 +325,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tune-file", default=os.environ.get("FFN_IGEMM_TUNE_FILE", ""),
                     help="igemm tuning table: loaded before the warm-up if it exists, written after it (profiling runs then skip the tuner's candidate launches)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3"])
+    ap.add_argument("--dtype", default="bf16x3", choices=["bf16", "f32", "bf16x3"],
+                    help="arithmetic mode of the timed region; default = the fastest mode that holds the 1e-3 latent tolerance on the N=50 fixtures")
+    ap.add_argument("--planted", type=float, default=3.0, help="gain of the planted denoiser path of the synthetic UNet weights (0 = purely random weights)")
+    ap.add_argument("--text", default="clip", choices=["clip", "table"], help="text encoder inside the timed region: real-size CLIP-shaped transformers model "
+                    "on the device (prompt cache off) or the table-lookup stand-in of the tests")
+    ap.add_argument("--extra-steps", dest="extra_steps", type=int, default=3, help="timed steps of the f32 / fast-mode legs")
     ap.add_argument("--model", default="sd21-base")
     ap.add_argument("--vae", default="sd")
     ap.add_argument("--num-step", dest="num_step", type=int, default=50)
@@ -318,10 +346,10 @@ def main():
     ap.add_argument("--cpu-skip-vae", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--fp8-conv", dest="fp8_conv", action="store_true", help="bf16 mode with e4m3 ResBlock convolutions (FFN_FP8) as the timed configuration")
-    ap.add_argument("--no-fp8-leg", dest="no_fp8_leg", action="store_true", help="skip the extra fp8-convolution measurement of the default run")
-    ap.add_argument("--no-parity", action="store_true", help="skip the parity-mode leg (f32 throughput + the headline mode's latent deviation)")
-    ap.add_argument("--parity-modes", default="f32,bf16x3", help="comma list; the first one is the reference of the deviation figures")
-    ap.add_argument("--parity-batch", type=int, default=8)
+    ap.add_argument("--fp8-leg", dest="fp8_leg", action="store_true", help="also measure the bf16 + e4m3-convolution variant under fast_modes (it bought "
+                    "nothing in the round-3 driver run, so it is off the default line)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity leg (f32 trajectory + throughput, the headline mode's latent deviation)")
+    ap.add_argument("--no-fast-modes", dest="no_fast_modes", action="store_true", help="skip the bf16 fast-mode leg")
     args = ap.parse_args()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
@@ -413,10 +441,15 @@ def main():
             skipped += (rows_g - 2) * F_REF_TAIL * (n - 1) / n
         n_dec = 1 if args.batch > 1 else 2
         f_exec = n * ((2 + rows_g) * F_UNET - skipped + rows_g * F_TCA) + 2 * F_VAE_ENC + n_dec * F_VAE_DEC
-        up2x_on = args.dtype in ("bf16", "bf16x3") and os.environ.get("FFN_UP2X", "1") != "0"
-        if up2x_on:             # nearest-2x + 3x3 conv evaluated as four 2x2 convolutions at low resolution: 4/9 of those FLOPs
+        # the state the models were actually built in (not the environment switch): sub-pixel form of nearest-2x + 3x3 conv
+        up2x_unet = any(b.up2 is not None for b in model.unet.up)
+        up2x_vae = any(b.up2 is not None for b in model.vae.dec_up)
+        up2x_on = up2x_unet or up2x_vae
+        if up2x_unet:           # nearest-2x + 3x3 conv evaluated as four 2x2 convolutions at low resolution: 4/9 of those FLOPs
             full_rows = 2 + (2 if reuse_on else rows_g)
-            f_exec -= n * (full_rows * F_UP2X + ((rows_g - 2) * F_UP2X_B if reuse_on else 0.0)) + n_dec * F_VAE_UP2X
+            f_exec -= n * (full_rows * F_UP2X + ((rows_g - 2) * F_UP2X_B if reuse_on else 0.0))
+        if up2x_vae:
+            f_exec -= n_dec * F_VAE_UP2X
         value = world * args.steps * args.concurrent * args.batch / dt
         line = {
             "metric": "edited images/sec/GPU @512px 50-step DDIM", "value": round(value, 4), "unit": "images/s", "n_gpus": world,
@@ -425,7 +458,9 @@ def main():
             "config": {"workload": f"SD-2.1-base topology ({args.model}) 512x512 FreeFine_generation edit, {args.num_step}-step DDIM schedule "
                                    f"(start_step={args.start_step}: per image {n} inversion forwards x 2 rows + {n} guided forwards x 4 rows, TCA blocks "
                                    f"10-15, masked CFG 7.5, eta=1) + VAE bracket; {args.batch} independent edits per UNet batch x "
-                                   f"{args.concurrent} HIP streams; seeded random weights",
+                                   f"{args.concurrent} HIP streams; seeded random weights" + (f" + planted denoiser path (gain {args.planted})" if args.planted > 0 else ""),
+                       "text_encoder": ("real-size CLIP-shaped transformers CLIPTextModel (23 layers, width 1024) on the device, prompt cache off: "
+                                        f"{model.text_encoder_calls} encoder calls by this pipeline so far") if args.text == "clip" else "table lookup stand-in",
                        "fp8_convolutions": bool(args.fp8_conv and args.dtype == "bf16"),
                        "images_per_gpu_per_step": args.concurrent * args.batch, "concurrent_streams": args.concurrent,
                        "images_per_unet_batch": args.batch, "unet_batch": 4 * args.batch, "hip_graph": not args.no_graph,
@@ -433,7 +468,7 @@ def main():
                        "reference_stream_reuse": ("on: the guided loop's reference row re-enters at up_blocks[2] from the state the inversion pass recorded for the "
                                                   "same (latent, timestep, prompt) and, at every step but the last, stops behind block 15's K / V projection (its eps is dead there); "
                                                   "outputs unchanged") if reuse_on else "off",
-                       "subpixel_upsample_convs": "on: nearest-2x + 3x3 conv = four 2x2 convolutions at low resolution (4/9 of the FLOPs), UNet and VAE decoder" if up2x_on else "off",
+                       "subpixel_upsample_convs": (f"nearest-2x + 3x3 conv = four 2x2 convolutions at low resolution (4/9 of the FLOPs): UNet {'on' if up2x_unet else 'off'}, VAE decoder {'on' if up2x_vae else 'off'}") if up2x_on else "off",
                        "vae_decode": "batched path decodes the edited latent only (the reference decodes the reference stream too and drops it unless return_ori)" if args.batch > 1 else "both streams, like the reference",
                        "algorithmic_tflop_per_image": round(f_img / 1e12, 1),
                        "whole_path_tflops_per_gpu": round(f_img * value / world / 1e12, 1),
@@ -484,26 +519,10 @@ def main():
                 f.write("kernel\tcalls\ttotal_ms\talgorithmic_TFLOP/s\talgorithmic_GB/s\n")
                 for k, c, ms, gf, gbs in table:
                     f.write(f"{k}\t{c}\t{ms:.3f}\t{gf:.1f}\t{gbs:.1f}\n")
-        fp8 = None
-        if not args.no_fp8_leg and not args.fp8_conv and world == 1 and args.dtype == "bf16":
-            rec, m8 = fp8_leg(args, device)
-            best = None
-            for i in range(2):                                  # the like-for-like bf16 figure: same layout, one stream, the second of two runs
-                torch.cuda.synchronize()
-                t0 = time.time()
-                with torch.cuda.stream(streams[0]):
-                    edit_once(models[0], args, 9000 + i)
-                streams[0].synchronize()
-                best = time.time() - t0
-            rec["bf16_same_layout"] = round(args.batch / best, 4)
-            fp8 = (rec, m8)
-        if not args.no_parity and world == 1 and args.dtype != "f32":
+        if not args.no_parity and world == 1:
             line["parity"] = parity_leg(args, device, model)
-        if fp8 is not None:
-            fp8_deviation(args, *fp8)
-            line["fp8_conv"] = fp8[0]
-            del fp8
-            torch.cuda.empty_cache()
+        if not args.no_fast_modes and world == 1 and args.dtype != "bf16":
+            line["fast_modes"] = fast_modes_leg(args, device)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline_leg(args)
         print(json.dumps(line), flush=True)

@@ -33,7 +33,7 @@ def main():
     if world > 1:
         torch.distributed.init_process_group("nccl", device_id=device)
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
-    model = FreeFinePipeline.from_pretrained(args.model, torch_dtype=dtype, device=device).to(device)
+    model = FreeFinePipeline.from_pretrained(args.model, torch_dtype=dtype, device=device, broadcast="auto").to(device)
     model._progress_bar_config = {"disable": True}
     model.scheduler = DDIMScheduler.from_config(model.scheduler.config)
     controller = Attention_Modulator(start_layer=10)

@@ -29,7 +29,7 @@ def main():
     device = torch.device(f"cuda:{local}")
     if world > 1:
         torch.distributed.init_process_group("nccl", device_id=device)
-    model = FreeFinePipeline.from_pretrained(args.model, torch_dtype=torch.float32 if args.dtype == "f32" else torch.bfloat16, device=device).to(device)
+    model = FreeFinePipeline.from_pretrained(args.model, torch_dtype=torch.float32 if args.dtype == "f32" else torch.bfloat16, device=device, broadcast="auto").to(device)
     model._progress_bar_config = {"disable": True}
     model.scheduler = DDIMScheduler.from_config(model.scheduler.config)
     controller = Attention_Modulator(start_layer=10)

@@ -91,7 +91,9 @@ def sync_tune_table(src=0, freeze=True):
     timing-based tuning on every rank: shapes in the table launch rank `src`'s choice, shapes first seen later take the deterministic
     rule -- identical tile / split-K choices on all ranks either way, hence bit-identical bf16 results across the ranks of a sharded
     run (the tuner picks by timing, which may differ per GPU).  Works on any backend: the table is a small int32 tensor shipped
-    with broadcast_object_list."""
+    with broadcast_object_list.
+    The freeze lasts until it is undone: `sync_tune_table.previous` holds the setting it replaced, `restore_tuning()` puts it back, and
+    `frozen_tuning()` is the same as a context manager (a later single-GPU phase of the same process can tune again)."""
     from . import ops
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
@@ -103,5 +105,36 @@ def sync_tune_table(src=0, freeze=True):
     else:
         n = box[0].shape[0]
     if freeze:
-        ops.tune_enable(False)
+        prev = ops.tune_enable(False)
+        if sync_tune_table.previous is None:
+            sync_tune_table.previous = prev
+        if dist.get_rank() == src:
+            print(f"[freefine_amd.dist] igemm tuning table of rank {src} ({n} shapes) installed on {dist.get_world_size()} ranks; timing-based tuning "
+                  "frozen (shapes seen later take the deterministic rule) until dist.restore_tuning()", flush=True)
     return n
+
+
+sync_tune_table.previous = None
+
+
+def restore_tuning():
+    """undo the freeze of sync_tune_table(freeze=True): timing-based tuning back to what it was before"""
+    from . import ops
+    if sync_tune_table.previous is not None:
+        ops.tune_enable(sync_tune_table.previous)
+        sync_tune_table.previous = None
+
+
+class frozen_tuning:
+    """with frozen_tuning(src=0): ...  -- the table of rank `src` on every rank and no timing-based tuning inside the block"""
+
+    def __init__(self, src=0):
+        self.src = src
+
+    def __enter__(self):
+        self.n = sync_tune_table(self.src, freeze=True)
+        return self
+
+    def __exit__(self, *exc):
+        restore_tuning()
+        return False

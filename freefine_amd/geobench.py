@@ -132,6 +132,10 @@ def warm_and_sync(model, batch, params, dsize=(512, 512), variant="2d", src=0):
             c = dict(cases[0])
             model.FreeFine_generation(c.pop("ori_img"), c.pop("ori_mask"), c.pop("coarse_input"), c.pop("target_mask"), c.pop("guidance_text"),
                                       params["guidance_scale"], params["eta"], seed=0, **kw, **c)
+        if batch > 1:               # the shapes of a trailing one-case batch too (other partial batches take the deterministic rule on every rank)
+            c = dict(cases[0])
+            model.FreeFine_generation(c.pop("ori_img"), c.pop("ori_mask"), c.pop("coarse_input"), c.pop("target_mask"), c.pop("guidance_text"),
+                                      params["guidance_scale"], params["eta"], seed=0, **kw, **c)
         model.unet.use_graph = was
         torch.cuda.synchronize()
     return FD.sync_tune_table(src)
@@ -187,6 +191,8 @@ def run(model, dst_base, batch=4, params=None, rank=0, world=1, check_exist=True
             flush()
     flush()
     merged = FD.gather_results(results) if world > 1 else results
+    if world > 1:
+        FD.restore_tuning()          # the freeze of warm_and_sync ends with the sharded run (a later phase of this process may tune again)
     if rank == 0:
         final = list(cl.existing_results) + merged
         new_data = {}

@@ -45,6 +45,7 @@ def _dilate(mask, k):
 
 class FreeFinePipeline:
     _progress_bar_config = {}
+    _warned_ref_cache = False
 
     def __init__(self, unet, vae, tokenizer, text_encoder, scheduler, device="cuda:0"):
         self.unet, self.vae, self.tokenizer, self.text_encoder, self.scheduler = unet, vae, tokenizer, text_encoder, scheduler
@@ -55,10 +56,15 @@ class FreeFinePipeline:
         self._gen = None
         self._mask_dev = {}
         self._batch_ctrls = {}
+        self.text_cache, self.text_cache_max, self._text_cache, self._text_on_device, self.text_encoder_calls = True, 256, {}, False, 0
         self.dedup_rows = True      # exact: identical (latent, text) rows of the CFG batch are evaluated once
         # exact: the guided loop's reference row re-enters the UNet from the state the inversion pass recorded for the same (latent,
         # timestep, "") triple instead of being recomputed from conv_in (HipUNet.forward, `reuse`); off = recompute like the reference
+        # Memory: the record holds the join-point state of every inversion step (about 0.7 GB per image in bf16, 1.4 GB in fp32 storage, at 64x64
+        # and 50 steps) until the guided loop consumes it; `ref_cache_max_bytes` (FFN_REF_CACHE_GB, default 64 GiB per pipeline) bounds it --
+        # above the bound the reference rows are recomputed -- and free_ref_cache() drops a record no guided loop will consume.
         self.reuse_ref_stream = True
+        self.ref_cache_max_bytes = int(float(os.environ.get("FFN_REF_CACHE_GB", "64")) * 2**30)
         self.drop_ref_tail = True    # with reuse: reference rows stop after the last K / V projection at every step but the last (their eps is dead)
         self._ref_cache = None
 
@@ -66,17 +72,18 @@ class FreeFinePipeline:
     # construction (freefine_batch_infer_2d.py:148-157)
     # ------------------------------------------------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, path, torch_dtype=torch.float32, device="cuda:0", seed=0, broadcast="auto", x3=False, fp8_conv=False, **kw):
+    def from_pretrained(cls, path, torch_dtype=torch.float32, device="cuda:0", seed=0, broadcast=False, x3=False, fp8_conv=False, **kw):
         """`path` is either a HF-layout Stable-Diffusion folder (unet/, vae/ safetensors + config.json; tokenizer/,
         text_encoder/ loaded through transformers when present) or "synthetic:<unet preset>[:<vae preset>]" for
         seeded random weights of that architecture (no checkpoints exist in the build environment).
         torch_dtype float32 -> exact-fp32 parity mode; float16/bfloat16 -> bf16 MFMA fast mode; float32 with x3=True -> the
         split-bf16 mode (fp32 activations, every UNet GEMM on three bf16 MFMAs per product term: fp32-level results at several
         times the fp32-MFMA rate; the VAE bracket runs in the same mode).
-        In a torch.distributed job (`broadcast="auto"`: whenever a process group with more than one rank is initialised) only
-        rank 0 reads / generates the UNet and VAE weights; the other ranks receive them over RCCL straight into device memory
-        (freefine_amd.dist.broadcast_state; bf16 payload for the matrices in fast mode) -- the reference has every rank read
-        the checkpoint itself (freefine_batch_infer_2d.py:149)."""
+        `broadcast` (OPT-IN; the GeoBench drivers pass broadcast="auto"): construction becomes a COLLECTIVE -- only rank 0 reads /
+        generates the UNet and VAE weights, every other rank of the default process group receives them over RCCL straight into device
+        memory (freefine_amd.dist.broadcast_state; bf16 payload for the matrices in fast mode), so ALL ranks must call it with the same
+        arguments ("auto": only when a process group with more than one rank is initialised).  The default (False) is the reference's
+        behaviour: every caller reads the checkpoint itself (freefine_batch_infer_2d.py:149), safe on a subset of ranks."""
         from . import dist as FD
         dtype = torch.float32 if torch_dtype == torch.float32 else torch.bfloat16
         shared = FD.active() if broadcast == "auto" else bool(broadcast)
@@ -142,6 +149,7 @@ class FreeFinePipeline:
         other = FreeFinePipeline(self.unet.share(), self.vae, self.tokenizer, self.text_encoder,
                                  DDIMScheduler.from_config(self.scheduler.config), self.device)
         other.noise_device, other.dedup_rows, other.reuse_ref_stream, other.drop_ref_tail = self.noise_device, self.dedup_rows, self.reuse_ref_stream, self.drop_ref_tail
+        other.text_cache, other._text_on_device = self.text_cache, self._text_on_device
         return other
 
     def _seed(self, seed):
@@ -252,9 +260,41 @@ class FreeFinePipeline:
 
     @torch.no_grad()
     def _encode_text(self, prompts):
-        ids = self.tokenizer(prompts, padding="max_length", max_length=77, return_tensors="pt").input_ids
-        out = self.text_encoder(ids)[0]
-        return out.to(self.device, torch.float32).contiguous()
+        """tokenizer + text encoder (model.py:536-567, 842-848).  A torch text encoder (transformers CLIPTextModel) is moved to the
+        pipeline's device on first use and fed device-side ids -- the reference's `.to(device)` does the same; from_pretrained used to leave it
+        on the host.  `text_cache` (default on): embeddings are kept per prompt string (an edit asks for "" five times and the GeoBench
+        drivers repeat object labels), at most `text_cache_max` entries, LRU; `text_cache = False` encodes every request."""
+        if isinstance(prompts, str):
+            prompts = [prompts]
+        prompts = list(prompts)
+        cache = self._text_cache if self.text_cache else None
+        missing = [q for q in dict.fromkeys(prompts) if cache is None or q not in cache]
+        fresh = {}
+        if missing:
+            enc = self.text_encoder
+            if isinstance(enc, torch.nn.Module) and not self._text_on_device:
+                enc.to(self.device)
+                self._text_on_device = True
+            ids = self.tokenizer(missing, padding="max_length", max_length=77, return_tensors="pt").input_ids
+            if isinstance(enc, torch.nn.Module):
+                ids = ids.to(self.device)
+            out = enc(ids)[0].to(self.device, torch.float32)
+            self.text_encoder_calls += 1
+            for j, q in enumerate(missing):
+                fresh[q] = out[j]
+                if cache is not None:
+                    cache[q] = out[j]
+                    while len(cache) > self.text_cache_max:
+                        cache.pop(next(iter(cache)))
+        rows = []
+        for q in prompts:
+            if q in fresh:
+                rows.append(fresh[q])
+            else:
+                v = cache.pop(q)            # re-insert: most recently used last
+                cache[q] = v
+                rows.append(v)
+        return torch.stack(rows).contiguous()
 
     @torch.no_grad()
     def get_text_embeddings(self, prompt):
@@ -329,6 +369,18 @@ class FreeFinePipeline:
                 cache["slots"].append([s.index_select(0, cache["idx"]) for s in self.unet.last_boundary])
             else:
                 noise_pred = self.unet(model_inputs, t, encoder_hidden_states=text)
+            if cache is not None and len(cache["slots"]) == 1:
+                # size guard (the record is 13.8 MB per image and step in bf16 at 64x64, twice that in fp32 storage, x 2.25 at 768^2): if the
+                # whole schedule would not fit the budget, stop recording -- the guided loop then recomputes the reference rows like the reference
+                first = cache["slots"][0]
+                per_step = sum(t_.numel() * t_.element_size() for s_ in first for t_ in (s_ if isinstance(s_, (tuple, list)) else (s_,)))
+                n_rec = num_actual_inference_steps if num_actual_inference_steps is not None else len(self.scheduler.timesteps)
+                if per_step * n_rec > self.ref_cache_max_bytes:
+                    if not FreeFinePipeline._warned_ref_cache:
+                        FreeFinePipeline._warned_ref_cache = True
+                        print(f"[freefine_amd] reference-stream record of {per_step * n_rec / 2**30:.1f} GiB exceeds ref_cache_max_bytes "
+                              f"({self.ref_cache_max_bytes / 2**30:.1f} GiB): recomputing the reference rows instead", flush=True)
+                    cache = None
             if guidance_scale > 1.:
                 eu, ec = noise_pred.chunk(2, dim=0)
                 noise_pred = ops.cfg_masked(eu.contiguous(), ec.contiguous(), None, guidance_scale)
@@ -338,6 +390,10 @@ class FreeFinePipeline:
         if return_intermediates:
             return latents, latents_list
         return latents
+
+    def free_ref_cache(self):
+        """drop the reference-stream record of the last inversion (for callers that invert without running a guided loop afterwards)"""
+        self._ref_cache = None
 
     def _take_ref_cache(self, refer_latents, n_act, text, ref_text_rows, kv=False):
         """the recorded reference stream of the inversion that produced `refer_latents` (checked by identity: guided step k reads

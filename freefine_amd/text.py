@@ -52,3 +52,24 @@ def make_text_embed(tokenizer, text_encoder):
     def f(prompts):
         return text_encoder(tokenizer(prompts, padding="max_length", max_length=77, return_tensors="pt").input_ids)[0]
     return f
+
+
+def clip_shaped_text_encoder(dim, seed=1234, layers=None):
+    """A REAL-SIZE text encoder for synthetic runs (bench.py): transformers' CLIPTextModel built from a config of the checkpoint's shape --
+    SD-2.1's OpenCLIP ViT-H text tower (width 1024, 23 layers = the penultimate-layer output the checkpoint ships, 16 heads, MLP 4096, gelu),
+    SD-1.x's CLIP ViT-L (768, 12 layers, 12 heads, 3072, quick_gelu) -- with seeded random weights (no checkpoints exist offline), so that the
+    text side of an edit costs what it costs with a checkpoint.  torch module: FreeFinePipeline moves it to its device on first use."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    if dim == 1024:
+        cfg = CLIPTextConfig(vocab_size=49408, hidden_size=1024, intermediate_size=4096, num_hidden_layers=layers or 23, num_attention_heads=16,
+                             max_position_embeddings=77, hidden_act="gelu", projection_dim=1024)
+    else:
+        cfg = CLIPTextConfig(vocab_size=49408, hidden_size=dim, intermediate_size=4 * dim, num_hidden_layers=layers or 12,
+                             num_attention_heads=max(1, dim // 64), max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=dim)
+    state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    enc = CLIPTextModel(cfg).eval()
+    torch.random.set_rng_state(state)
+    for q in enc.parameters():
+        q.requires_grad_(False)
+    return enc

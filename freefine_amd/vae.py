@@ -7,6 +7,8 @@ kernel's pad=0 / stride=2 geometry, the decoder's nearest-2x upsample is fused i
 GEMM -> row softmax -> GEMM with K / V^T used directly as the GEMMs' W operands.  The 0.18215 latent scale is folded into
 quant_conv / post_quant_conv at pack time.
 """
+import os
+
 import torch
 
 from . import ops
@@ -100,7 +102,7 @@ class HipVAE:
             b.res = [self._res(st, f"decoder.up_blocks.{i}.resnets.{j}") for j in range(cfg.layers_per_block + 1)]
             b.up = self._conv(st, f"decoder.up_blocks.{i}.upsamplers.0.conv") if i < n - 1 else None
             b.up2 = None                                    # sub-pixel form of `nearest-2x -> 3x3 conv` (4/9 of the FLOPs, ops.pack_conv3x3_up2x)
-            if b.up is not None and (self.dtype == torch.bfloat16 or self.x3):
+            if b.up is not None and (self.dtype == torch.bfloat16 or self.x3) and os.environ.get("FFN_UP2X", "1") != "0":      # same switch as HipUNet
                 wu = st[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"].float().to(self.device)
                 if ops.up2x_eligible(wu.shape[1], wu.shape[0], 192):
                     b.up2 = ops.pack_conv3x3_up2x(wu, self.dtype, x3=self.x3)

@@ -70,3 +70,59 @@ def oracle_pipe(unet_name="tiny", seed=0):
 
 
 BRANCH_CODE = {"plain": 0, "tca:tca": 1, "tca:mmsa": 1, "cross_local": 2, "ssa": 3, "sdsa": 3}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The metric's own schedules (N = 50): SURVEY 8(a) call-site table.  G9 = the REFERENCE's loops on the tiny topology
+# (tools/gen_golden.py run_g9), G10 = OraclePipeline at FULL size (tools/gen_fullsize_traj.py; the oracle is pinned by G1-G9).
+# "planted": freefine_amd.weights.plant_denoiser_path on the seeded state, so that a schedule that starts from pure noise
+# (start_step 0 / 1) is a denoising trajectory with O(1) latents instead of a 14.6x amplification of the DDPM noise.
+# ----------------------------------------------------------------------------------------------------------------
+def n50_cases():
+    ori, tgt, draw, cons_sup, cons_tgt = mask_inputs()
+    return [
+        # (name, hook, unet, planted gain, kwargs)
+        ("n50_edit_s0", "edit", "tiny", 3.0, dict(method_type="tca", draw_mask=draw, use_auto_draw=False, cons_area=None, reduce_inp_artifacts=False,
+                                                  end_step=50, num_step=50, start_step=0, end_scale=0.0, guidance_text="a cup", guidance_scale=7.5, eta=1.0)),
+        # freefine_batch_infer_2d.py:212-230 (non-wrapping variant: cons_area >= ori_mask)
+        ("n50_edit_s35", "edit", "tiny", 0.0, dict(method_type="tca", draw_mask=None, use_auto_draw=True, cons_area=cons_sup, reduce_inp_artifacts=True,
+                                                   end_step=50, num_step=50, start_step=35, end_scale=0.0, guidance_text="", guidance_scale=7.5, eta=1.0)),
+        # freefine_batch_infer_3d_depth.py:144-162 (non-wrapping variant: cons_area >= ori_mask)
+        ("n50_edit_s15", "edit", "tiny", 0.0, dict(method_type="tca", draw_mask=draw, use_auto_draw=False, cons_area=cons_sup, reduce_inp_artifacts=True,
+                                                   end_step=50, num_step=50, start_step=15, end_scale=0.0, guidance_text="a cup", guidance_scale=7.5, eta=1.0)),
+        # freefine_batch_infer_bggen_2d.py:149,166-180
+        ("n50_bg_s1", "bggen", "tiny", 3.0, dict(method_type="tca", end_step=35, num_step=50, start_step=1, end_scale=0.5)),
+        # Appearance_transfer.ipynb cell 5 / SURVEY 8d C4
+        ("n50_cmp_s15", "compose", "tiny", 0.0, dict(method_type="tca", appearance_transfer=True, dil_completion=False)),
+    ]
+
+
+def tiny_state(unet_name, seed, planted):
+    """the seeded tiny-topology UNet state of the goldens (+ the planted denoiser path when planted > 0)"""
+    from oracle import sd_unet
+    st = sd_unet.init_unet(sd_unet.unet_config(unet_name), seed=seed).state_dict()
+    if planted > 0:
+        from freefine_amd.config import UNetConfig
+        from freefine_amd.weights import plant_denoiser_path
+        st = plant_denoiser_path(st, UNetConfig.preset(unet_name), planted)
+    return st
+
+
+def fullsize_inputs():
+    H = 512
+    ori_img, coarse, _ = synth_images(H, H)
+    ori, tgt, draw = rect_mask(H, H, 200, 304, 96, 200, 255), rect_mask(H, H, 200, 304, 160, 264, 255), rect_mask(H, H, 184, 320, 144, 288, 1)
+    cons_sup = (np.maximum(ori, tgt) // 255).astype(np.uint8)
+    return ori_img, coarse, ori, tgt, draw, cons_sup
+
+
+def fullsize_cases():
+    ori_img, coarse, ori, tgt, draw, cons_sup = fullsize_inputs()
+    return {
+        # the GeoBench-2D call site at full size: SD-2.1-base topology, 512^2, N = 50, start_step = 35 (15 + 15 forwards), default-init weights
+        "fs_edit_s35": (0.0, dict(method_type="tca", draw_mask=None, use_auto_draw=True, cons_area=cons_sup, reduce_inp_artifacts=True,
+                                  end_step=50, num_step=50, start_step=35, end_scale=0.0, guidance_text="", guidance_scale=7.5, eta=1.0)),
+        # the metric's schedule at full size: N = 50, start_step = 0 (50 + 50 forwards), planted denoiser path
+        "fs_edit_s0": (3.0, dict(method_type="tca", draw_mask=draw, use_auto_draw=False, cons_area=None, reduce_inp_artifacts=False,
+                                 end_step=50, num_step=50, start_step=0, end_scale=0.0, guidance_text="a photo of a cup", guidance_scale=7.5, eta=1.0)),
+    }

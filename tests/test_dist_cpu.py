@@ -43,7 +43,12 @@ n_tab = FD.sync_tune_table()
 tab = ops.tune_table_export()
 # rank 0's table REPLACES the local one (no rank-local leftovers), and timing-based tuning is frozen on every rank
 assert n_tab == 3 and tab.shape[0] == 3 and sorted(tab[:, 1].tolist()) == [4096, 8192, 98304] and sorted(tab[:, -2].tolist()) == [1, 6, 13], tab
-assert ops.tune_enable(True) is False
+assert ops.tune_enable(False) is False          # frozen ...
+FD.restore_tuning()                              # ... until restored: back to the setting the freeze replaced (tuning on)
+assert ops.tune_enable(True) is True and FD.sync_tune_table.previous is None
+with FD.frozen_tuning():
+    assert ops.tune_enable(False) is False
+assert ops.tune_enable(True) is True
 if rank == 0:
     print("DIST_OK", len(res))
 dist.destroy_process_group()

@@ -90,3 +90,37 @@ def test_g5_composition():
                                         start_step=6, seed=11, dil_factor=9, end_scale=0.5, **kw)
         assert traj_dev(traj, g[f"{name}_traj"]) < TOL, name
         assert np.abs(img[::4, ::4].astype(int) - g[f"{name}_img"].astype(int)).max() <= 1, name
+
+
+def _run_oracle_n50(name, hook, unet_name, planted, kw):
+    from golden_cases import tiny_state
+    ori_img, coarse, img2 = synth_images()
+    ori, tgt, *_ = mask_inputs()
+    kw = dict(kw)
+    op = oracle_pipe(unet_name)
+    op.unet.load_state_dict(tiny_state(unet_name, 0, planted))
+    if hook == "edit":
+        text, gs, eta = kw.pop("guidance_text"), kw.pop("guidance_scale"), kw.pop("eta")
+        img, _, traj = op.freefine_generation(ori_img, ori, coarse, tgt, text, gs, eta, seed=42, **kw)
+    elif hook == "bggen":
+        img, traj = op.freefine_background_generation(ori_img, OM.dilate_mask(ori // 255, 30), "empty scene", 7.5, 1.0, seed=7, **kw)
+    else:
+        oris, tgts = compose_masks()
+        img, traj = op.freefine_compose([ori_img, img2], oris, tgts, coarse, ["a cup", "a dog"], 7.5, 1.0, end_step=50, num_step=50,
+                                        start_step=15, seed=11, dil_factor=9, end_scale=0.5, **kw)
+    return img, [t if t.ndim == 3 or hook == "edit" else t[0] for t in traj]
+
+
+def test_g9_metric_schedules_n50():
+    """the oracle's loops on the METRIC's schedules (N = 50; start_step 0 / 35 / 15 for the edit, 1 for background generation, 15 for the
+    composition -- the reference's call sites) against the trajectories the REFERENCE produced (tools/gen_golden.py run_g9):
+    ABSOLUTE latent L-inf at every step (|latent| <= 13 on these trajectories)."""
+    from golden_cases import n50_cases
+    g = np.load(os.path.join(GOLD, "g9_n50_loops.npz"))
+    for name, hook, unet_name, planted, kw in n50_cases():
+        img, traj = _run_oracle_n50(name, hook, unet_name, planted, kw)
+        ref = g[f"{name}_traj"]
+        assert len(traj) == len(ref)
+        dev = max((a.float() - torch.from_numpy(b)).abs().max().item() for a, b in zip(traj, ref))
+        assert dev < 2e-4, (name, dev)
+        assert np.abs(img[::4, ::4].astype(int) - g[f"{name}_img"].astype(int)).max() <= 1, name

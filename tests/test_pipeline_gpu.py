@@ -480,3 +480,74 @@ def test_composition_stored_reference_kv_is_exact(gpu, graph):
     for j in range(2):
         assert traj_dev(outs[True][j], as_np(outs[False][j])) < 1e-4, j
     assert traj_dev(outs[True][0], g[f"{name}_traj"]) < TOL
+
+
+@pytest.mark.parametrize("x3", [False, True], ids=["f32", "bf16x3"])
+def test_metric_schedules_n50_vs_reference_golden(gpu, x3):
+    """The METRIC's own schedules (N = 50) against trajectories the REFERENCE produced (tests/golden/g9_n50_loops.npz, tools/gen_golden.py
+    run_g9): edit at start_step 0 (50 + 50 forwards), 35 (GeoBench-2D, freefine_batch_infer_2d.py:212-230), 15 (GeoBench-3D,
+    freefine_batch_infer_3d_depth.py:144-162), background generation at start_step 1 (freefine_batch_infer_bggen_2d.py:166-180) and the
+    composition at start_step 15.  Gate: ABSOLUTE latent L-inf <= 1e-3 at EVERY step, in the fp32 parity mode and in the split-bf16 mode
+    (the mode bench.py's headline is timed in), through the captured hipGraphs."""
+    from golden_cases import n50_cases, tiny_state
+    g = np.load(os.path.join(GOLD, "g9_n50_loops.npz"))
+    ori_img, coarse, img2 = synth_images()
+    ori, tgt, *_ = mask_inputs()
+    for name, hook, unet_name, planted, kw in n50_cases():
+        kw = dict(kw)
+        model = make_pipe(gpu, unet_name, hook, graph=True, ustate=tiny_state(unet_name, 0, planted), x3=x3)
+        if hook == "edit":
+            text, gs, eta = kw.pop("guidance_text"), kw.pop("guidance_scale"), kw.pop("eta")
+            img = model.FreeFine_generation(ori_img, ori, coarse, tgt, text, gs, eta, verbose=True, seed=42, return_intermediates=True, **kw)
+        elif hook == "bggen":
+            img = model.FreeFine_background_generation(ori_img, model.dilate_mask(ori // 255, 30), "empty scene", 7.5, 1.0, verbose=True, seed=7,
+                                                       return_intermediates=True, **kw)
+        else:
+            oris, tgts = compose_masks()
+            img = model.FreeFine_cross_image_composition([ori_img, img2], oris, tgts, coarse, ["a cup", "a dog"], 7.5, 1.0, end_step=50,
+                                                         num_step=50, start_step=15, verbose=True, seed=11, dil_factor=9, end_scale=0.5,
+                                                         return_intermediates=True, **kw)
+        ref = g[f"{name}_traj"]
+        dev = traj_dev(model.last_intermediates, ref)
+        print(f"{'split-bf16' if x3 else 'fp32'} {name} ({len(ref) - 1} guided steps, |latent| max {np.abs(ref).max():.1f}): "
+              f"ABSOLUTE latent L-inf vs reference golden {dev:.2e}")
+        assert dev < TOL, name
+        assert np.abs(img[::4, ::4].astype(int) - g[f"{name}_img"].astype(int)).max() <= 1, name
+
+
+@pytest.mark.parametrize("case", ["fs_edit_s35", "fs_edit_s0"])
+def test_full_size_n50_schedules_vs_oracle_fixture(gpu, case):
+    """BASELINE's metric configuration end to end at FULL size on its own schedule: SD-2.1-base UNet (865.9 M parameters), 512x512 images,
+    N = 50 with start_step = 35 (the GeoBench-2D call site: 15 inversion + 15 guided forwards) and start_step = 0 (the metric's "50-step":
+    50 + 50 forwards; planted denoiser path, freefine_amd.weights.plant_denoiser_path, so that the trajectory is a denoising one), TCA in
+    blocks 10-15, masked CFG 7.5, eta = 1 -- against the trajectory OraclePipeline produced in the build container
+    (tests/golden/g10_fullsize_*.npz, tools/gen_fullsize_traj.py).  Gate: ABSOLUTE latent L-inf <= 1e-3 at every step of the edited row, in
+    fp32 parity mode and in the split-bf16 mode (bench.py's headline mode); the bf16 fast mode is measured and printed, not gated."""
+    from golden_cases import fullsize_cases, fullsize_inputs
+    from freefine_amd.config import UNetConfig
+    from freefine_amd.weights import plant_denoiser_path
+    from oracle import sd_unet
+    g = np.load(os.path.join(GOLD, f"g10_fullsize_{case}.npz"))
+    ori_img, coarse, ori, tgt, draw, cons_sup = fullsize_inputs()
+    planted, kw = fullsize_cases()[case]
+    kw = dict(kw)
+    text, gs, eta = kw.pop("guidance_text"), kw.pop("guidance_scale"), kw.pop("eta")
+    ust = sd_unet.init_unet(sd_unet.unet_config("sd21-base"), seed=0).state_dict()
+    if planted > 0:
+        ust = plant_denoiser_path(ust, UNetConfig.preset("sd21-base"), planted)
+    ref_e, ref_r = g["traj_edit"], g["traj_ref"]
+    for mode, dtype, x3 in (("fp32", torch.float32, False), ("split-bf16", torch.float32, True), ("bf16", torch.bfloat16, False)):
+        model = make_pipe(gpu, "sd21-base", "edit", dtype=dtype, graph=True, ustate=ust, x3=x3)
+        img = model.FreeFine_generation(ori_img, ori, coarse, tgt, text, gs, eta, verbose=True, seed=42, return_intermediates=True, **kw)
+        traj = torch.stack([t.detach().float().cpu() for t in model.last_intermediates])
+        assert traj.shape[0] == ref_e.shape[0] == kw["num_step"] - kw["start_step"] + 1
+        d_e = (traj[:, 0] - torch.from_numpy(ref_e)).abs().flatten(1).max(1).values
+        d_r = (traj[::5, 1] - torch.from_numpy(ref_r)).abs().flatten(1).max(1).values
+        print(f"full-size {case}, {mode}: ABSOLUTE latent L-inf vs oracle fixture over {traj.shape[0] - 1} guided steps: edited row max {d_e.max():.2e} "
+              f"(final {d_e[-1]:.2e}), reference row {d_r.max():.2e}; |latent| max {np.abs(ref_e).max():.2f}; image max |diff| "
+              f"{np.abs(img[::4, ::4].astype(int) - g['img'].astype(int)).max()}")
+        if mode != "bf16":
+            assert d_e.max() < TOL and d_r.max() < TOL, (case, mode)
+            assert np.abs(img[::4, ::4].astype(int) - g["img"].astype(int)).max() <= 1
+        del model
+        torch.cuda.empty_cache()

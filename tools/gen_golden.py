@@ -605,8 +605,70 @@ def run_g8():
     np.savez_compressed(os.path.join(GOLD, "g8_dpt.npz"), **out)
 
 
+# --------------------------------------------------------------------------------------------------------------
+# G9: the reference's loops on the METRIC's schedules (N = 50; call sites: SURVEY 8a table): tiny topology, tests/golden_cases.n50_cases
+# --------------------------------------------------------------------------------------------------------------
+def run_g9(A, Mo):
+    from tests.golden_cases import n50_cases, tiny_state
+    ori_img, coarse, img2 = synth_images()
+    ori, tgt, draw, cons_sup, cons_tgt = mask_inputs()
+    out, report = {}, []
+
+    def capture(p, attr, cap):
+        orig = getattr(p, attr)
+
+        def f(*a, **k):
+            k["return_intermediates"] = True
+            im, lst = orig(*a, **k)
+            cap["traj"] = lst
+            return im, None
+        setattr(p, attr, f)
+
+    for name, hook, unet_name, planted, kw in n50_cases():
+        kw = dict(kw)
+        p = make_ref_pipe(A, Mo, hook, unet_name)
+        st = tiny_state(unet_name, 0, planted)
+        p.unet.load_state_dict(st)
+        op = oracle_pipe(unet_name)
+        op.unet.load_state_dict(st)
+        cap = {}
+        if hook == "edit":
+            text, gs, eta = kw.pop("guidance_text"), kw.pop("guidance_scale"), kw.pop("eta")
+            capture(p, "forward_sampling", cap)
+            img, _ = p.FreeFine_generation(ori_img, ori, coarse, tgt, text, gs, eta, verbose=True, return_ori=True, seed=42, **kw)
+            o_img, _, o_traj = op.freefine_generation(ori_img, ori, coarse, tgt, text, gs, eta, seed=42, **kw)
+            traj = cap["traj"]
+        elif hook == "bggen":
+            hole = p.dilate_mask(ori // 255, 30)
+            capture(p, "forward_sampling_background_gen", cap)
+            img = p.FreeFine_background_generation(ori_img, hole, "empty scene", 7.5, 1.0, verbose=True, seed=7, **kw)
+            o_img, o_traj = op.freefine_background_generation(ori_img, hole, "empty scene", 7.5, 1.0, seed=7, **kw)
+            traj = [t if t.ndim == 3 else t[0] for t in cap["traj"]]
+            o_traj = [t if t.ndim == 3 else t[0] for t in o_traj]
+        else:
+            (o1, o2), (t1, t2) = compose_masks()
+            Mo.seed_everything(11)
+            lst = p.DDIM_inversion_func_compose(img=coarse, compose_imgs=[ori_img, img2], prompt="", num_step=50, start_step=15, verbose=True)
+            capture(p, "forward_sampling_compose", cap)
+            img, _ = p.Details_Preserving_regeneration_compose(coarse, lst, ["a cup", "a dog"], [o1, o2], [t1, t2], None, num_steps=50,
+                                                               start_step=15, end_step=50, eta=1.0, guidance_scale=7.5, verbose=True,
+                                                               dil_factor=9, end_scale=0.5, **kw)
+            o_img, o_traj = op.freefine_compose([ori_img, img2], [o1, o2], [t1, t2], coarse, ["a cup", "a dog"], 7.5, 1.0, end_step=50, num_step=50,
+                                                start_step=15, seed=11, dil_factor=9, end_scale=0.5, **kw)
+            traj = [t if t.ndim == 3 else t[0] for t in cap["traj"]]
+            o_traj = [t if t.ndim == 3 else t[0] for t in o_traj]
+        dev = max((a.float() - b.float()).abs().max().item() for a, b in zip(traj, o_traj))
+        amax = max(a.abs().max().item() for a in traj)
+        report.append((name, len(traj) - 1, dev, amax, int(np.abs(img.astype(int) - o_img.astype(int)).max())))
+        out[f"{name}_traj"] = torch.stack(traj).numpy()
+        out[f"{name}_img"] = img[::4, ::4].copy()
+    np.savez_compressed(os.path.join(GOLD, "g9_n50_loops.npz"), **out)
+    for r in report:
+        print(f"[G9] {r[0]:14s} {r[1]:2d} guided steps: oracle vs reference ABSOLUTE latent deviation {r[2]:.3e} (|latent| max {r[3]:.2f}), uint8 image max diff {r[4]}")
+
+
 if __name__ == "__main__":
-    only = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g6b", "g7", "g8"]
+    only = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g9"]
     torch.set_grad_enabled(False)
     A, Mo = RH.import_reference()
     if "g1" in only:
@@ -625,3 +687,5 @@ if __name__ == "__main__":
         run_g7()
     if "g8" in only:
         run_g8()
+    if "g9" in only:
+        run_g9(A, Mo)
