@@ -24,7 +24,9 @@ def main():
     ap.add_argument("--model", default="synthetic:sd21-base")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="f32 = parity mode (the reference runs fp32 here), bf16 = fast mode")
     ap.add_argument("--batch", type=int, default=4, help="cases edited together in one UNet batch")
-    ap.add_argument("--variant", default="2d", choices=["2d", "3d_depth"])
+    ap.add_argument("--variant", default="2d", choices=["2d", "3d_depth", "3d_rgb"],
+                    help="3d_rgb: the GeoBench-3D edit with the coarse input rendered here (DepthAnything depth + point-cloud warp) instead of read from disk")
+    ap.add_argument("--depth-model", default="synthetic:vitl", help="3d_rgb: a Depth-Anything state dict (.pth) or synthetic:<vits|vitb|vitl>")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank, local = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
@@ -44,7 +46,17 @@ def main():
     model.enable_xformers_memory_efficient_attention()
     model.unet.use_graph = True
     from freefine_amd import geobench
-    geobench.run(model, args.base_dir, batch=args.batch, rank=rank, world=world, variant=args.variant)
+    depth_model = None
+    if args.variant == "3d_rgb":
+        from freefine_amd import depth as FDp
+        if args.depth_model.startswith("synthetic:"):
+            dcfg = FDp.depth_config(args.depth_model.split(":")[1])
+            dstate = FDp.synthetic_state(dcfg, seed=0)
+        else:
+            dstate = torch.load(args.depth_model, map_location="cpu", weights_only=True)
+            dcfg = FDp.depth_config({384: "vits", 768: "vitb", 1024: "vitl"}[dstate["pretrained.cls_token"].shape[-1]])
+        depth_model = FDp.HipDepthAnything(dcfg, dstate, dtype=dtype, device=device)
+    geobench.run(model, args.base_dir, batch=args.batch, rank=rank, world=world, variant=args.variant, depth_model=depth_model)
     if world > 1:
         torch.distributed.destroy_process_group()
 

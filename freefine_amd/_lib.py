@@ -60,6 +60,11 @@ class CtrlStepDesc(C.Structure):
     ]
 
 
+class SplatXform(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("translate", C.c_float * 3), ("rotate", C.c_float * 9), ("scale", C.c_float * 3),
+                ("tan_half_fov", C.c_float)]
+
+
 class PackDesc(C.Structure):
     _fields_ = [
         ("src", C.c_void_p), ("dst", C.c_void_p), ("src_row", C.c_int * 16),
@@ -109,6 +114,10 @@ SYMBOLS = {
     "ffn_cast": (_i, [_vp, _i, _i, _vp, _vp, _l]),
     "ffn_eltwise": (_i, [_vp, _i, _i, _vp, _vp, _vp, _l]),
     "ffn_resize_bilinear": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
+    "ffn_splat_lift": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f]),
+    "ffn_splat_project": (_i, [_vp, _vp, _vp, _i, C.POINTER(SplatXform)]),
+    "ffn_splat_bin": (_i, [_vp, _i, _vp, _i, _f, _i, _i, _vp, _vp, _vp]),
+    "ffn_splat_render": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
     "ffn_image_to_nhwc": (_i, [_vp, _i, _vp, _vp, _l, _i]),
     "ffn_nhwc_to_image": (_i, [_vp, _i, _vp, _vp, _i, _i, _i]),
 }

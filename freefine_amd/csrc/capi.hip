@@ -18,6 +18,7 @@
 #include "igemm.h"
 #include "igemm_p8.h"
 #include "norms.h"
+#include "splat.h"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -1401,4 +1402,44 @@ extern "C" int ffn_nhwc_to_image(void* stream, int dtype, const void* src, float
     else if (dtype == FFN_BF16) LAUNCH(nhwc_to_image_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)src, dst, B, HW, ld);
     else return fail(FFN_EINVAL, "nhwc_to_image: bad dtype");
     return check_launch("nhwc_to_image");
+}
+
+// ---- point-cloud warp of the 3-D front end (splat.h) ----------------------------------------------------------------
+extern "C" int ffn_splat_lift(void* stream, const float* depth, const int* idx, float* pts, int n, int W, int H, float fx, float fy) {
+    REQUIRE(depth && idx && pts, "splat_lift: null operand");
+    REQUIRE(n > 0 && W > 0 && H > 0 && (long)W * H < (1l << 31) && fx != 0.f && fy != 0.f, "splat_lift: bad shape / focal length");
+    LAUNCH(splat_lift_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), depth, idx, pts, n, W, H, fx, fy);
+    return check_launch("splat_lift");
+}
+extern "C" int ffn_splat_project(void* stream, const float* pts, float* proj, int n, const ffn_splat_xform* x) {
+    REQUIRE(pts && proj && x, "splat_project: null operand");
+    REQUIRE(n > 0, "splat_project: empty cloud");
+    SplatXform X;
+    for (int i = 0; i < 3; ++i) { X.c[i] = x->center[i]; X.t[i] = x->translate[i]; X.s[i] = x->scale[i]; }
+    for (int i = 0; i < 9; ++i) X.R[i] = x->rotate[i];
+    REQUIRE(x->tan_half_fov > 0.f, "splat_project: tan_half_fov must be positive");
+    X.inv_tan = 1.f / x->tan_half_fov;
+    LAUNCH(splat_project_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts, proj, n, X);
+    return check_launch("splat_project");
+}
+extern "C" int ffn_splat_bin(void* stream, int fill, const float* proj, int n, float radius, int W, int H, int* counts, const int* offs, int* list) {
+    REQUIRE(proj && counts, "splat_bin: null operand");
+    REQUIRE(!fill || (offs && list), "splat_bin: the filling pass needs the tile offsets and the list");
+    REQUIRE(n > 0 && W > 0 && H > 0 && radius > 0.f, "splat_bin: bad shape / radius");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (fill) LAUNCH(splat_bin_kernel<true>, dim3(grid_for(n)), dim3(256), 0, s, proj, n, radius, W, H, counts, offs, list);
+    else LAUNCH(splat_bin_kernel<false>, dim3(grid_for(n)), dim3(256), 0, s, proj, n, radius, W, H, counts, offs, list);
+    return check_launch("splat_bin");
+}
+extern "C" int ffn_splat_render(void* stream, const float* proj, const float* rgb, const int* offs, const int* list, float radius, int K, int W, int H,
+                                float* image, int* idx_sum, uint8_t* covered) {
+    REQUIRE(proj && rgb && offs && list && image && idx_sum && covered, "splat_render: null operand");
+    REQUIRE(K >= 1 && K <= 32, "splat_render: points per pixel K=%d out of range (1 .. 32)", K);
+    REQUIRE(W > 0 && H > 0 && radius > 0.f, "splat_render: bad shape / radius");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int tiles = ((W + 15) / 16) * ((H + 15) / 16);
+    if (K <= 8) LAUNCH(splat_render_kernel<8>, dim3(tiles), dim3(256), 0, s, proj, rgb, offs, list, radius, K, W, H, image, idx_sum, covered);
+    else if (K <= 16) LAUNCH(splat_render_kernel<16>, dim3(tiles), dim3(256), 0, s, proj, rgb, offs, list, radius, K, W, H, image, idx_sum, covered);
+    else LAUNCH(splat_render_kernel<32>, dim3(tiles), dim3(256), 0, s, proj, rgb, offs, list, radius, K, W, H, image, idx_sum, covered);
+    return check_launch("splat_render");
 }

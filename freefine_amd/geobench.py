@@ -29,6 +29,9 @@ VARIANTS = {
     "2d": dict(params=GEOBENCH_2D, annotations="annotations_2d.json", gen_subdir=GEN_SUBDIR, results="generated_results_freefine_2d.json"),
     "3d_depth": dict(params=GEOBENCH_3D_DEPTH, annotations="annotations.json", gen_subdir="Geo-Bench-3D/Gen_results_FreeFine_depth",
                      results="generated_results_freefine_depth.json"),
+    # the same edit with the coarse input rendered here from the RGB image + transform (depth network + point-cloud warp on the GPU)
+    "3d_rgb": dict(params=GEOBENCH_3D_DEPTH, annotations="annotations.json", gen_subdir="Geo-Bench-3D/Gen_results_FreeFine_depth_rgb",
+                   results="generated_results_freefine_depth_rgb.json"),
 }
 
 
@@ -77,6 +80,50 @@ def load_case_3d_depth(case, dst_base, dsize=(512, 512)):
     return dict(ori_img=read_and_resize_img(case["ori_img_path"], dsize), ori_mask=read_and_resize_mask(case["ori_mask_path"], dsize),
                 coarse_input=coarse, target_mask=target_mask, guidance_text=case["obj_label"],
                 draw_mask=read_and_resize_mask(case["draw_mask"], dsize), use_auto_draw=False, reduce_inp_artifacts=True, cons_area=target_mask)
+
+
+def monocular_depth(img, depth_model, translate_factor=0.1, side=518):
+    """get_monocular_depth_anything (the reference's callers: evaluation/DiffusionHandles/eval_geobench.py:163-215, src/utils/ui_utils.py:380-401):
+    shorter side -> `side` (a multiple of 14, aspect kept, both sides multiples of 14), ImageNet normalisation, the depth network, bilinear back
+    to the image size, `depth.max() - depth` (relative -> absolute), pushed back by translate_factor * max so that no point sits at z = 0.
+    The resampling around the network is torch (plumbing); the network is freefine_amd.depth.HipDepthAnything."""
+    import torch
+    import torch.nn.functional as F
+    h, w = img.shape[:2]
+    sc = side / min(h, w)
+    nh, nw = max(14, int(round(h * sc / 14)) * 14), max(14, int(round(w * sc / 14)) * 14)
+    dev = depth_model.device if hasattr(depth_model, "device") else "cuda:0"
+    x = torch.from_numpy(np.ascontiguousarray(img)).to(dev).permute(2, 0, 1)[None].float() / 255.0
+    x = F.interpolate(x, size=(nh, nw), mode="bicubic", align_corners=False)
+    mean = torch.tensor([0.485, 0.456, 0.406], device=x.device)[None, :, None, None]
+    std = torch.tensor([0.229, 0.224, 0.225], device=x.device)[None, :, None, None]
+    d = depth_model(((x - mean) / std).contiguous()).float()
+    d = F.interpolate(d[None] if d.ndim == 3 else d, (h, w), mode="bilinear", align_corners=False)[0, 0]
+    d = d.max() - d
+    d = d + d.max() * translate_factor
+    return d.clamp_min(0).cpu().numpy().astype(np.float32)
+
+
+def load_case_3d_rgb(case, dst_base, dsize=(512, 512), depth_model=None, focal_length=550.0):
+    """a GeoBench-3D case whose coarse edit is built HERE from the RGB image and its 3-D transform instead of being read from disk
+    (freefine_batch_infer_3d_depth.py:121 reads coarse3d_depth_anything/...png, which evaluation/FreeFine/get_3d_transform_correspondence.py
+    rendered beforehand): DepthAnything depth -> point-cloud warp of the object's pixels (freefine_amd.warp3d, geo_utils.py:427-528) over the
+    inpainted background.  edit_param = [tx, ty, tz (pixels at the 512 reference size), rx, ry, rz (degrees), sx, sy, sz] (:235-247); the
+    translation is passed relative to the image size, as the reference does (edit_param / LENGTH)."""
+    from . import warp3d
+    assert depth_model is not None, "the 3d_rgb variant needs a depth model (freefine_amd.depth.HipDepthAnything or depth_anything.dpt.DepthAnything)"
+    ori_img = read_and_resize_img(case["ori_img_path"], dsize)
+    ori_mask = read_and_resize_mask(case["ori_mask_path"], dsize)
+    bg = read_and_resize_img(osp.join(dst_base, INP_SUBDIR, str(case["da_n"]), str(case["ins_id"]), "inp_img.png"), dsize)
+    depth = monocular_depth(ori_img, depth_model)
+    ep = [float(v) for v in case["edit_param"]]
+    tf = [ep[0] / 512.0, ep[1] / 512.0, ep[2] / 512.0, ep[3], ep[4], ep[5], ep[6], ep[7], ep[8]]
+    m2 = ori_mask if ori_mask.ndim == 2 else ori_mask[:, :, 0]
+    coarse, target_mask = warp3d.coarse_edit_3d(ori_img, m2, depth, tf, bg, focal_length=focal_length * dsize[0] / 512.0)
+    draw = ndimage_max(np.maximum(target_mask, (m2 > 0).astype(np.uint8) * 255), 9)
+    return dict(ori_img=ori_img, ori_mask=ori_mask, coarse_input=coarse, target_mask=target_mask, guidance_text=case.get("obj_label", ""),
+                draw_mask=(draw > 0).astype(np.uint8), use_auto_draw=False, reduce_inp_artifacts=True,
+                cons_area=np.maximum(target_mask, (m2 > 0).astype(np.uint8) * 255))
 
 
 def _prefetch(cases, dst_base, depth, dsize, loader=None):
@@ -141,7 +188,7 @@ def warm_and_sync(model, batch, params, dsize=(512, 512), variant="2d", src=0):
     return FD.sync_tune_table(src)
 
 
-def run(model, dst_base, batch=4, params=None, rank=0, world=1, check_exist=True, verbose=True, dsize=(512, 512), variant="2d"):
+def run(model, dst_base, batch=4, params=None, rank=0, world=1, check_exist=True, verbose=True, dsize=(512, 512), variant="2d", depth_model=None):
     """edit every case of the variant's annotation file that this rank owns; rank 0 writes the variant's result JSON
     (2d: annotations_2d.json -> generated_results_freefine_2d.json; 3d_depth: annotations.json -> generated_results_freefine_depth.json).
     Returns the merged result list (on every rank)."""
@@ -181,7 +228,9 @@ def run(model, dst_base, batch=4, params=None, rank=0, world=1, check_exist=True
             results.append(dict(c, gen_img_path=path, key=f'{c["da_n"]}/{c["ins_id"]}/{c["edit_ins"]}'))
         pending.clear()
 
-    for case, inputs, err in _prefetch(mine, dst_base, 2 * batch, dsize, load_case_3d_depth if variant == "3d_depth" else load_case):
+    loader = {"2d": load_case, "3d_depth": load_case_3d_depth,
+              "3d_rgb": lambda c, b, d: load_case_3d_rgb(c, b, d, depth_model=depth_model)}[variant]
+    for case, inputs, err in _prefetch(mine, dst_base, 2 * batch, dsize, loader):
         if err is not None:
             if verbose:
                 print(f'[geobench] skipped {case["da_n"]}/{case["ins_id"]}/{case["edit_ins"]}: {err}')

@@ -277,9 +277,15 @@ class FreeFinePipeline:
                 self._text_on_device = True
             ids = self.tokenizer(missing, padding="max_length", max_length=77, return_tensors="pt").input_ids
             if isinstance(enc, torch.nn.Module):
+                # a torch encoder runs every distinct prompt ON ITS OWN: a library GEMM may pick another kernel / summation order for another
+                # batch size, and the exact reductions downstream (reference-stream reuse, CFG row de-duplication) compare embeddings bit for
+                # bit -- the "" of the inversion call must equal the "" of the guided call whatever else was asked for beside it
                 ids = ids.to(self.device)
-            out = enc(ids)[0].to(self.device, torch.float32)
-            self.text_encoder_calls += 1
+                out = torch.cat([enc(ids[j:j + 1])[0] for j in range(len(missing))]).to(self.device, torch.float32)
+                self.text_encoder_calls += len(missing)
+            else:
+                out = enc(ids)[0].to(self.device, torch.float32)
+                self.text_encoder_calls += 1
             for j, q in enumerate(missing):
                 fresh[q] = out[j]
                 if cache is not None:

@@ -189,6 +189,29 @@ int ffn_eltwise(void* stream, int dtype, int op, const void* a, const void* b, v
  * align_corners=True) as called by depth_anything/blocks.py:147-149 and dpt.py:132, 165.  relu != 0 applies max(., 0) (dpt.py:166). */
 int ffn_resize_bilinear(void* stream, int dtype, const void* x, void* y, int B, int Hin, int Win, int Hout, int Wout, int C, int relu);
 
+/* ---- point-cloud warp of the 3-D coarse edit ------------------------------------------------------------
+ * The arithmetic of IntegratedP3DTransRasterBlendingFull (src/utils/geo_utils.py:427-528): depth-lifted object pixels -> rigid transform about
+ * the cloud's centre -> FoV-perspective projection -> pytorch3d-style disc splat (PointsRasterizer: the K nearest covering points per pixel,
+ * AlphaCompositor with weights 1 - d^2 / r^2).  pytorch3d is absent from the build image: the restatement is PARITY UNPINNED (property-tested
+ * and checked against oracle/warp3d.py).  All buffers fp32 / int32, device memory.
+ *   ffn_splat_lift     pts[n][4] = (-(i - W/2) z / fx, -(j - H/2) z / fy, z, 0) for the masked pixels idx[n] = j * W + i (geo_utils.py:436-457)
+ *   ffn_splat_project  proj[n][4] = (x_ndc, y_ndc, z_view, 0): view = ((p - center + translate) . rotate) * scale + center, row vectors,
+ *                      ndc = view.xy / (view.z * tan_half_fov)  (geo_utils.py:343-378, 399-425, 478-481)
+ *   ffn_splat_bin      tile binning (16 x 16 pixel tiles, tiles = ceil(W/16) * ceil(H/16)): fill = 0 adds to counts[tile] the number of discs
+ *                      whose bounding box touches the tile; fill = 1 writes the point ids to list[offs[tile] + k] (counts = zeroed cursor,
+ *                      offs = exclusive scan of the counting pass with the total at offs[tiles])
+ *   ffn_splat_render   image[H][W][3] (fp32, composited colours), idx_sum[H][W] (sum of the K point ids, -1 per empty slot: what the
+ *                      reference's mask test reads, geo_utils.py:517) and covered[H][W] (any point)  (geo_utils.py:482-517) */
+typedef struct ffn_splat_xform {
+    float center[3], translate[3], rotate[9] /* row-major, applied as p . R */, scale[3];
+    float tan_half_fov;
+} ffn_splat_xform;
+int ffn_splat_lift(void* stream, const float* depth, const int* idx, float* pts, int n, int W, int H, float fx, float fy);
+int ffn_splat_project(void* stream, const float* pts, float* proj, int n, const ffn_splat_xform* x);
+int ffn_splat_bin(void* stream, int fill, const float* proj, int n, float radius, int W, int H, int* counts, const int* offs, int* list);
+int ffn_splat_render(void* stream, const float* proj, const float* rgb, const int* offs, const int* list, float radius, int K, int W, int H,
+                     float* image, int* idx_sum, uint8_t* covered);
+
 /* ---- normalisation ------------------------------------------------------------------------------------------- */
 /* `silu` of ffn_groupnorm / ffn_gn_apply is a flag word: FFN_NORM_SILU applies SiLU; FFN_NORM_OUT_PAIR (fp32 input only) writes y as the
  * bf16 PAIR rows [B*HW][2C] = [hi | lo] an FFN_BF16X3 GEMM reads (no separate ffn_split_pair pass).  ffn_layernorm_pair: the same for LayerNorm. */

@@ -125,4 +125,7 @@ def fullsize_cases():
         # the metric's schedule at full size: N = 50, start_step = 0 (50 + 50 forwards), planted denoiser path
         "fs_edit_s0": (3.0, dict(method_type="tca", draw_mask=draw, use_auto_draw=False, cons_area=None, reduce_inp_artifacts=False,
                                  end_step=50, num_step=50, start_step=0, end_scale=0.0, guidance_text="a photo of a cup", guidance_scale=7.5, eta=1.0)),
+        # BASELINE.json configs[0], "SD-2.1 single 512x512 object-reposition edit, 20 DDIM steps, CPU path": the CPU run itself (20 + 20 forwards)
+        "fs_edit_n20": (3.0, dict(method_type="tca", draw_mask=draw, use_auto_draw=False, cons_area=None, reduce_inp_artifacts=False,
+                                  end_step=20, num_step=20, start_step=0, end_scale=0.0, guidance_text="a photo of a cup", guidance_scale=7.5, eta=1.0)),
     }

@@ -2,7 +2,9 @@
 same op on identical seeded inputs.  Tolerances: fp32 mode <= 2e-5 of the output scale (exact-fp32 MFMA, different
 summation order only); bf16 mode compares against the same op evaluated on bf16-rounded inputs, <= 1.5e-2."""
 import math
+import os
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -621,7 +623,7 @@ def _production_masks(S, kind, g):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("hook", ["edit", "bggen"])
 @pytest.mark.parametrize("kind", ["rect", "rand"])
-@pytest.mark.parametrize("S,heads", [(4096, 5), (1024, 10)])
+@pytest.mark.parametrize("S,heads", [(4096, 5), (1024, 10), (9216, 5)])
 def test_attention_tca_production_shapes(gpu, dtype, hook, kind, S, heads):
     """The TCA pass tables of the guided loop at the shapes BASELINE config 2 runs them (SD-2.1: S = 4096 / h = 5 and S = 1024 / h = 10,
     d = 64, B = 4 rows [u_e, u_r, c_e, c_r]) against the fp64 statement of /root/reference/src/utils/attention.py:1043-1091 (edit) and
@@ -1105,3 +1107,64 @@ def test_fp8_groupnorm_and_every_configuration(gpu):
                 assert relerr(out, ref + rb.double()[:, None] + r.double()) < tol(torch.bfloat16), (cfg, H, Cin, sk)
     finally:
         lib.ffn_igemm_force_config(-1)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
+def test_ffn_attn_vs_reference_g1_fixture(gpu, mode):
+    """ffn_attn, driven by Attention_Modulator's own pass tables, against the numbers the REFERENCE's Attention_Modulator produced
+    (tests/golden/g1_attention.npz: Temporal_contextal_attention / _bg / _compose, modulate_local_cross_attn / _compose and the plain branch of
+    /root/reference/src/utils/attention.py at S = 64 / 256, 8 x 8 and 5 x 16 heads, uint8 and float masks, with and without upcast): the
+    kernel tied to the reference's numbers directly, not through an in-test restatement."""
+    from test_oracle_golden import g1_inputs, g1_masks
+    from freefine_amd import ops
+    from freefine_amd.attention import Attention_Modulator
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g1_attention.npz"))
+    dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+    x3 = mode == "bf16x3"
+    limit = {"f32": 2e-5, "bf16x3": 1e-4, "bf16": 4e-2}[mode]
+    ncase = len([k for k in g.files if k.endswith("_meta")])
+    worst = {}
+    for ci in range(ncase):
+        heads, d, S, is_float, upcast = (int(v) for v in g[f"c{ci}_meta"])
+        cg = float(g[f"c{ci}_cg"][0])
+        src, tgt, src2, tgt2 = g1_masks("float" if is_float else "uint8")
+        q4, k4, v4, kt, vt_, kc, vc = g1_inputs(ci, heads, d, S)
+        scale = d ** -0.5
+        cg_dev = torch.tensor([cg], dtype=torch.float32, device=gpu)
+        dev = lambda t: t.to(gpu, dtype).contiguous()
+        q, k, vT = dev(q4), dev(k4), ops.transpose(dev(v4))
+
+        def run(hook, method, is_cross, kk=None, vv=None, setup=None):
+            m = Attention_Modulator(start_layer=10)
+            m.num_att_layers, m.cur_att_layer = 32, 20 + (1 if is_cross else 0)              # block 10: inside layer_idx
+            m.method, m.context_guidance = method, cg
+            m.use_tca, m.local_edit = (not is_cross), is_cross
+            m.fg_retain_mask, m.fg_retain_mask_st2, m.fg_ref_mask, m.local_edit_region = tgt.clone(), tgt.clone(), src.clone(), tgt.clone()
+            if setup:
+                setup(m)
+            kq = k if kk is None else dev(kk)
+            vq = vT if vv is None else ops.transpose(dev(vv))
+            plan = m.plan(hook, is_cross, "up", 4, S, heads, gpu)
+            return ops.attention(q, kq, vq, heads, scale, plan["passes"], w_dev=cg_dev if plan["needs_cg"] else None, x3=x3)
+
+        def compose(m):
+            m.src_masks, m.tgt_masks = torch.stack([src, src2]), torch.stack([tgt, tgt2, 1 - torch.maximum(tgt, tgt2)])
+            m.prompt_length = 3
+        outs = {}
+        for method in ("tca", "mmsa"):
+            outs[f"edit_{method}"] = run("edit", method, False)
+            outs[f"bg_{method}"] = run("bggen", method, False)
+            outs[f"compose_{method}"] = run("compose", method, False, setup=compose)
+        outs["cross_local"] = run("edit", None, True, kt, vt_)
+        outs["cross_compose"] = run("compose", None, True, kc, vc, setup=compose)
+        outs["plain"] = ops.attention(q, k, vT, heads, scale, None, x3=x3)
+        for name, o in outs.items():
+            o = o.float().cpu()
+            sub = torch.from_numpy(g[f"c{ci}_{name}_sub"])
+            e = (o[:, ::5, ::3] - sub).abs().max().item() / max(1.0, sub.abs().max().item())
+            worst[name] = max(worst.get(name, 0.0), e)
+            assert e < limit, (ci, name, e)
+            if mode != "bf16":
+                s1, _ = g[f"c{ci}_{name}_sum"]
+                assert abs(o.double().sum().item() - s1) < 2e-3 * (1 + abs(s1)), (ci, name)
+    print(f"ffn_attn vs the reference's G1 outputs, {mode}: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))

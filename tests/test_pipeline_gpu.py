@@ -214,6 +214,19 @@ def test_geobench_harness_on_gpu(gpu, tmp_path):
                         variant="3d_depth")
     assert len(res3) == 3 and os.path.exists(os.path.join(root3, "generated_results_freefine_depth.json"))
     assert all(np.asarray(Image.open(r["gen_img_path"])).shape == (128, 128, 3) for r in res3)
+    # GeoBench-3D from the RGB image + transform (BASELINE configs[4]'s front end): DepthAnything depth -> point-cloud warp -> guided edit
+    from freefine_amd import depth as FDp
+    dcfg = FDp.depth_config("tiny")
+    dmodel = FDp.HipDepthAnything(dcfg, FDp.synthetic_state(dcfg, seed=3), dtype=torch.float32, device=gpu)
+    root4 = str(tmp_path / "geo3d_rgb")
+    geobench.make_synthetic_dataset(root4, n_images=1, edits_per_image=2, size=128, seed=6, with_3d=True, with_backgrounds=True)
+    case = geobench.load_json(os.path.join(root4, "annotations.json"))["0000"]["instances"]["0"]["0"]
+    inp = geobench.load_case_3d_rgb(dict(case, da_n="0000", ins_id="0", edit_ins="0"), root4, (128, 128), depth_model=dmodel)
+    assert inp["coarse_input"].shape == (128, 128, 3) and inp["target_mask"].max() == 255 and 0 < (inp["target_mask"] > 0).mean() < 0.5
+    res4 = geobench.run(model, root4, batch=2, params=dict(num_step=10, start_step=3, end_step=10), dsize=(128, 128), verbose=False,
+                        variant="3d_rgb", depth_model=dmodel)
+    assert len(res4) == 2 and os.path.exists(os.path.join(root4, "generated_results_freefine_depth_rgb.json"))
+    assert all(np.isfinite(np.asarray(Image.open(r["gen_img_path"])).astype(float)).all() for r in res4)
 
 
 def test_image_batched_background_generation_matches_single(gpu):
@@ -515,11 +528,12 @@ def test_metric_schedules_n50_vs_reference_golden(gpu, x3):
         assert np.abs(img[::4, ::4].astype(int) - g[f"{name}_img"].astype(int)).max() <= 1, name
 
 
-@pytest.mark.parametrize("case", ["fs_edit_s35", "fs_edit_s0"])
+@pytest.mark.parametrize("case", ["fs_edit_s35", "fs_edit_s0", "fs_edit_n20"])
 def test_full_size_n50_schedules_vs_oracle_fixture(gpu, case):
     """BASELINE's metric configuration end to end at FULL size on its own schedule: SD-2.1-base UNet (865.9 M parameters), 512x512 images,
     N = 50 with start_step = 35 (the GeoBench-2D call site: 15 inversion + 15 guided forwards) and start_step = 0 (the metric's "50-step":
-    50 + 50 forwards; planted denoiser path, freefine_amd.weights.plant_denoiser_path, so that the trajectory is a denoising one), TCA in
+    50 + 50 forwards; planted denoiser path, freefine_amd.weights.plant_denoiser_path, so that the trajectory is a denoising one) and BASELINE
+    configs[0]'s 20-step plumbing run (N = 20, start_step = 0: the CPU run of that configuration IS the fixture), TCA in
     blocks 10-15, masked CFG 7.5, eta = 1 -- against the trajectory OraclePipeline produced in the build container
     (tests/golden/g10_fullsize_*.npz, tools/gen_fullsize_traj.py).  Gate: ABSOLUTE latent L-inf <= 1e-3 at every step of the edited row, in
     fp32 parity mode and in the split-bf16 mode (bench.py's headline mode); the bf16 fast mode is measured and printed, not gated."""

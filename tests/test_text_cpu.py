@@ -34,4 +34,6 @@ def test_clip_shaped_text_encoder_is_a_transformers_clip_text_model_of_the_check
     assert e.shape == (2, 77, 1024) and e.dtype == torch.float32 and torch.isfinite(e).all()
     assert not torch.equal(e[0], e[1])
     e2 = clip_shaped_text_encoder(1024, layers=2)(ByteTokenizer()(["a photo of a cup"]).input_ids)[0]
-    assert torch.allclose(e2[0], e[0], atol=1e-5)               # seeded: every rank builds the same encoder
+    assert torch.equal(e2[0], e[0])                             # seeded: every rank builds the same encoder; one prompt per encoder call
+    p2 = _pipe(enc)
+    assert torch.equal(p2._encode_text(["", "x", "a photo of a cup"])[2], e[0]) and p2.text_encoder_calls == 3   # bit-identical whatever is beside it

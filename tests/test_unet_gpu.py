@@ -153,6 +153,30 @@ def test_unet_full_size_bf16_fast_mode_vs_oracle(gpu):
     assert err < 6e-2
 
 
+def test_unet_full_size_768px_latent_96x96(gpu):
+    """BASELINE configs[4]'s resolution: SD-2.1-base topology at the 96x96 latent of a 768x768 image (S = 9216 / 2304 / 576 / 144: the top
+    level has 144 key tiles, the LDS rings of the ping-pong attention wrap 36 times; M = 18432 ... 288 rows per GEMM), two plain rows (the
+    inversion forward), against the CPU oracle: fp32 parity mode and the split-bf16 mode gated at 2e-4 of the output scale, bf16 printed.
+    (The TCA pass tables at S = 9216 are checked per kernel, test_ops_gpu.py::test_attention_tca_production_shapes: the oracle's modulated
+    attention materialises [4 h, S, S] scores, 20 GB of host memory at this size.)"""
+    from freefine_amd.config import UNetConfig
+    from freefine_amd.unet import HipUNet
+    from oracle import sd_unet
+    torch.set_num_threads(max(8, min(32, torch.get_num_threads())))
+    onet = sd_unet.init_unet(sd_unet.unet_config("sd21-base"), seed=0)
+    D = onet.cfg.cross_attention_dim
+    x, enc = rng_tensor(41, (2, 4, 96, 96)), rng_tensor(42, (2, 77, D))
+    ref = onet(x, torch.tensor(481), enc)
+    for dtype, x3, tol in ((torch.float32, False, 2e-4), (torch.float32, True, 2e-4), (torch.bfloat16, False, 6e-2)):
+        hnet = HipUNet(UNetConfig.preset("sd21-base"), onet.state_dict(), dtype=dtype, device=gpu, x3=x3)
+        out = hnet(x.to(gpu), 481, enc.to(gpu))
+        err = relerr(out, ref)
+        print(f"full-size sd21-base @96x96 (768 px), {dtype}{' split-bf16' if x3 else ''}: max |diff| / max |ref| = {err:.3e}")
+        assert err < tol, dtype
+        del hnet
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("hook", ["edit", "bggen"])
 def test_unet_full_size_modulated_64x64(gpu, hook):
     """SD-2.1-base topology at the 64x64 latent with the attention-modulation hooks ON (TCA in blocks 10-15 at S = 4096 / 1024 with
