@@ -79,11 +79,10 @@ __device__ unsigned long long pp_trace[256 * 64];   // tools/native/pp_bench.hip
 // the LDS double buffer are assigned separately --
 //     A_hi[c] -> A slot 0 (read by T0, T1; re-staged during T2)          A_lo[c] -> A slot 1 (read by T2; re-staged during the next T1)
 //     W_hi[c] -> B slot c & 1 (read by T0, T2)                            W_lo[c] -> the other B slot (read by T1)
-// which keeps every re-staging >= 2 phases behind the slot's last read (the WAR rule above) -- and a tile only requests what is not already
-// there: T2 requests A_hi and W_hi of the next chunk (the full set), T0 requests W_lo (B pieces: phases 1-2) for T1 and, since round 4, A_lo
-// (A pieces: phases 3-4) for T2 -- two tiles ahead: A slot 1 is idle from the previous T2 on, so the request need not wait for T1, whose
-// phase-4 wait used to sit one phase behind it; T1 requests nothing.  18 instead of 27 LDS-DMA pieces per chunk and wave in a kernel whose
-// bound is the issue of those pieces.  K slices of a split-K launch are whole chunks.
+// which keeps every re-staging >= 2 phases behind the slot's last read (the WAR rule above) -- and a tile only requests what the NEXT tile
+// does not already have: T2 requests A_hi and W_hi of the next chunk (the full set), T0 only W_lo (B pieces: phases 1-2, then nothing; its
+// phase-4 wait is vmcnt(0)), T1 only A_lo (A pieces: phases 3-4; its phase-1 wait is vmcnt(0)).  18 instead of 27 LDS-DMA pieces per chunk
+// and wave in a kernel whose bound is the issue of those pieces.  K slices of a split-K launch are whole chunks.
 // Output and residual are fp32: accumulators start at bias + row bias + fp32 residual, the epilogue stores 16 bytes per lane through the
 // same lane permutation as the split-K slabs.
 // F8 (FFN_FP8, 3x3 convolutions): fp8 e4m3 operands in the bf16 byte geometry (the library passes a bf16-shaped view: K, Cin, Kpad in
@@ -182,8 +181,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     const int cpt_rcp = X3 ? ((1 << 20) + cpt - 1) / cpt : (65536 + cpt - 1) / cpt;
     const int lo_bytes = X3 ? p.a_lo * 2 : 0;
     int ka = 0, tap_ky = 0, tap_kx = 0, tap_off = 0;  // of K tile l_kt; set by k_position()
-    auto k_position = [&](int ahead = 0) {            // ahead = 1 (X3 T0): the tile AFTER the loader's next one (A_lo of the current chunk)
-        const int kt = l_k0 + l_kt + ahead;
+    auto k_position = [&]() {
+        const int kt = l_k0 + l_kt;
         if constexpr (X3) {                           // chunk order: tile r of a tap = (chunk r / 3, segment r % 3); segments 0, 1 read the hi plane, 2 the lo plane
             const int tap = AMODE == AMODE_DENSE ? 0 : (kt * cpt_rcp) >> 20;
             const int r = kt - tap * cpt;
@@ -599,12 +598,9 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
             const int nty = ty == 2 ? 0 : ty + 1, ncp = ty == 2 ? cp ^ 1 : cp;
             ra = ty == 2 ? 1 : 0;
             rb = ty == 1 ? cp ^ 1 : cp;
+            la = nty == 2 ? 1 : 0;
             lb = nty == 1 ? ncp ^ 1 : ncp;
-            // A_lo[c] (A slot 1, read by T2 only) is requested during T0 -- TWO tiles ahead of its first read, a whole tile earlier than the
-            // slot's WAR rule demands (last read: phase 4 of the previous T2; staged in phases 3-4 of T0) -- instead of during T1, whose
-            // phase-4 wait then sat one phase behind the request (round 4; T1 requests nothing at all now).  T2 stages A_hi[c+1] as before.
-            la = ty == 0 ? 1 : 0;
-            needA = more && ty != 1;
+            needA = more && nty != 1;
             needB = more && nty != 2;
         }
 
@@ -633,9 +629,9 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
 #pragma unroll
             for (int i = 0; i < NB1; ++i) issue_b(i, lb);
             pp_wait_vmcnt<NB1>();                     // A-high of THIS K tile (requested in phase 4 of the previous one) has landed
-        } else if (!(X3 && more)) {
-            pp_wait_vmcnt<0>();                       // last K tile of the stream
-        }                                             // (X3 T1: its operands landed behind T0's phase-4 wait; the A_lo pieces T0 requested stay in flight)
+        } else {
+            pp_wait_vmcnt<0>();                       // last K tile of the stream, or an X3 T1 (nothing requested for it after the previous tile's wait)
+        }
         __builtin_amdgcn_sched_barrier(0);
         pp_barrier();
         mfma_rows(I0_t{});
@@ -662,7 +658,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         read_a(ra, a_rd1, 0);
         read_b(rb, b_rd1);
         if (needA) {
-            k_position(X3 && ty == 0 ? 1 : 0);
+            k_position();
             issue_a(0, la);
             issue_a(1, la);
         }
@@ -683,8 +679,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
             // B and A-low of the next K tile have landed (this phase's A-high pieces, and the next output tile's 6 column-vector
             // loads, may still be in flight)
             if (PP_ABL == 9 && c_kt < 2) {}           // timing experiment: no wait in the two K tiles behind the stores (results garbage)
-            else if (!needA) pp_wait_vmcnt<0>();      // X3 T1: nothing requested; the A_lo pieces of T0 (and, behind an output-tile switch, the column vectors) land here
-            else if (X3 && ty == 0) pp_wait_vmcnt<NA>();      // X3 T0: its B pieces (phases 1-2) have landed, the A_lo pieces of phases 3-4 stay in flight; no tile switch here
+            else if (!needA) pp_wait_vmcnt<0>();      // X3 T0: only B pieces were requested (phases 1-2); the loader never switches output tiles here
             else if (switched) pp_wait_vmcnt<NA - 2 + (SPLIT ? 0 : 6)>();
             else pp_wait_vmcnt<NA - 2>();
         }

@@ -1143,9 +1143,10 @@ def test_ffn_attn_vs_reference_g1_fixture(gpu, mode):
             if setup:
                 setup(m)
             kq = k if kk is None else dev(kk)
-            vq = vT if vv is None else ops.transpose(dev(vv))
+            Sk = kq.shape[1]
+            vq = vT if vv is None else ops.transpose(dev(vv), ld_dst=(Sk + 7) // 8 * 8)          # V^T rows padded to whole 16-byte chunks (77 -> 80)
             plan = m.plan(hook, is_cross, "up", 4, S, heads, gpu)
-            return ops.attention(q, kq, vq, heads, scale, plan["passes"], w_dev=cg_dev if plan["needs_cg"] else None, x3=x3)
+            return ops.attention(q, kq, vq, heads, scale, plan["passes"], Sk=Sk, w_dev=cg_dev if plan["needs_cg"] else None, x3=x3)
 
         def compose(m):
             m.src_masks, m.tgt_masks = torch.stack([src, src2]), torch.stack([tgt, tgt2, 1 - torch.maximum(tgt, tgt2)])

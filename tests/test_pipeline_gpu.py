@@ -526,6 +526,19 @@ def test_metric_schedules_n50_vs_reference_golden(gpu, x3):
               f"ABSOLUTE latent L-inf vs reference golden {dev:.2e}")
         assert dev < TOL, name
         assert np.abs(img[::4, ::4].astype(int) - g[f"{name}_img"].astype(int)).max() <= 1, name
+        if name in ("n50_edit_s0", "n50_edit_s35"):
+            # the path bench.py times: the same edit as image 0 of an IMAGE-BATCHED call (FreeFine_generation_batch, other images beside it)
+            cases = _batch_cases()
+            c0 = dict(ori_img=ori_img, ori_mask=ori, coarse_input=coarse, target_mask=tgt, guidance_text=text, draw_mask=kw.get("draw_mask"))
+            for k_ in ("use_auto_draw", "cons_area", "reduce_inp_artifacts"):
+                c0[k_] = kw[k_]
+                for c_ in cases:
+                    c_[k_] = kw[k_] if k_ != "cons_area" or kw[k_] is None else np.ones_like(kw[k_])
+            bkw = {k_: kw[k_] for k_ in ("end_step", "num_step", "start_step", "method_type", "end_scale")}
+            model.FreeFine_generation_batch([c0, cases[1], cases[2]], gs, eta, seeds=[42, 7, 1234], return_intermediates=True, **bkw)
+            devb = traj_dev(model.last_intermediates[0], ref)
+            print(f"{'split-bf16' if x3 else 'fp32'} {name}, image 0 of a batch of 3: ABSOLUTE latent L-inf vs reference golden {devb:.2e}")
+            assert devb < TOL, name
 
 
 @pytest.mark.parametrize("case", ["fs_edit_s35", "fs_edit_s0", "fs_edit_n20"])

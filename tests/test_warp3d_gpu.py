@@ -56,7 +56,7 @@ def test_point_cloud_warp_invariants_and_repeatability(gpu):
     u[:-1, :] |= m[1:, :]
     u[:-1, :-1] |= m[1:, 1:]
     assert np.array_equal(cov0 > 0, u)
-    ext = (np.nonzero(m.any(0))[0].ptp())                      # object extent in pixels along x
+    ext = np.ptp(np.nonzero(m.any(0))[0])                      # object extent in pixels along x
     out, _, cov = warp3d.point_cloud_warp(img, depth, [-5 / ext, 0, 0, 0, 0, 0, 1, 1, 1], f, f, mask, True, r, 5, device=gpu, return_covered=True)
     assert np.array_equal(cov, np.roll(cov0, 5, axis=1))
     assert np.abs(out.astype(int) - np.roll(base, 5, axis=1).astype(int)).max() <= 1
