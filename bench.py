@@ -171,6 +171,10 @@ def roofline_leg(model, args):
                share_of_timed_kernels=round(d["total_ms"] / total_ms, 3))
     if traffic_note:
         out["traffic_note"] = traffic_note
+    targs = name[name.find("<") + 1:name.rfind(">")].split(", ") if "igemm_pp_kernel<" in name else []
+    if len(targs) > 5 and targs[5] == "true":     # SPLIT: one event-timed launch = two kernels
+        out["launch_note"] = ("split-K launch: avg_launch_us brackets the slab kernel AND igemm_splitk_reduce_kernel (rocprofv3 lists them separately: "
+                              "their two averages add up to this figure; achieved = algorithmic FLOPs / that sum)")
     # the next kernels by total time, same definitions (the first two trade places from run to run: 10.6 % vs 10.7 % of the timed kernels)
     out["next_kernels"] = [dict(kernel=k, achieved=round(tf, 2), frac=round(tf / peak, 4), share_of_timed_kernels=round(ms / total_ms, 3))
                            if tf > 0 else

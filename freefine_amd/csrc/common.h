@@ -175,6 +175,22 @@ __device__ __forceinline__ f32x2_t gelu_erf_fast2(f32x2_t x) {
     const f32x2_t cdf = f32x2_t{copysignf(half_erf[0], x[0]), copysignf(half_erf[1], x[1])} + 0.5f;
     return x * cdf;
 }
+// gelu_erf_fast (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7: accurate enough for fp32 results) on two values at once -- the GEGLU epilogue of the
+// split-bf16 GEMMs (round 4): everything but the two v_rcp / v_exp as packed f32 instructions, same arithmetic per value as the scalar form.
+__device__ __forceinline__ f32x2_t gelu_erf26_2(f32x2_t x) {
+    const f32x2_t z = f32x2_t{fabsf(x[0]), fabsf(x[1])} * 0.70710678118654752440f;
+    f32x2_t t = z * 0.3275911f + 1.0f;
+    t = f32x2_t{__builtin_amdgcn_rcpf(t[0]), __builtin_amdgcn_rcpf(t[1])};
+    f32x2_t poly = t * 1.061405429f + (-1.453152027f);
+    poly = poly * t + 1.421413741f;
+    poly = poly * t + (-0.284496736f);
+    poly = poly * t + 0.254829592f;
+    const f32x2_t zz = z * z * (-1.44269504088896340736f);
+    const f32x2_t e = f32x2_t{__builtin_amdgcn_exp2f(zz[0]), __builtin_amdgcn_exp2f(zz[1])};
+    const f32x2_t half_erf = (poly * t) * e * (-0.5f) + 0.5f;               // 0.5 * erf(|x| / sqrt 2)
+    const f32x2_t cdf = f32x2_t{copysignf(half_erf[0], x[0]), copysignf(half_erf[1], x[1])} + 0.5f;
+    return x * cdf;
+}
 template <typename T>
 __device__ __forceinline__ float gelu_for(float x) {
     if constexpr (sizeof(T) == 2) return gelu_erf_fast(x);

@@ -458,9 +458,9 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
                     const int vo2 = m0 + i * 16 + pr < p.M ? (pr * p.ldo + 4 * pg) * 2 : OOB;
 #pragma unroll
                     for (int j = 0; j + 1 < FN; j += 2) {
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * gelu_erf_fast(acc[i][j + 1][r]);
+                        const f32x2_t g01 = gelu_erf26_2(f32x2_t{acc[i][j + 1][0], acc[i][j + 1][1]}) * f32x2_t{acc[i][j][0], acc[i][j][1]};
+                        const f32x2_t g23 = gelu_erf26_2(f32x2_t{acc[i][j + 1][2], acc[i][j + 1][3]}) * f32x2_t{acc[i][j][2], acc[i][j][3]};
+                        const float v[4] = {g01[0], g01[1], g23[0], g23[1]};
                         u32x2 hi, lo;
                         hi[0] = pack_bf16x2(v[0], v[1]);
                         hi[1] = pack_bf16x2(v[2], v[3]);

@@ -9,6 +9,7 @@ usage (/root/reference/evaluation/FreeFine/freefine_batch_infer_2d.py:141-173, 2
                     rank read the checkpoint itself, :149)
   gather_results    all_gather_object of the per-rank result dicts (:243), merged by key on every rank
 """
+import sys
 import math
 
 import torch
@@ -110,7 +111,7 @@ def sync_tune_table(src=0, freeze=True):
             sync_tune_table.previous = prev
         if dist.get_rank() == src:
             print(f"[freefine_amd.dist] igemm tuning table of rank {src} ({n} shapes) installed on {dist.get_world_size()} ranks; timing-based tuning "
-                  "frozen (shapes seen later take the deterministic rule) until dist.restore_tuning()", flush=True)
+                  "frozen (shapes seen later take the deterministic rule) until dist.restore_tuning()", file=sys.stderr, flush=True)
     return n
 
 

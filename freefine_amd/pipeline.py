@@ -12,6 +12,7 @@ comparable with the CPU oracle on identical seeds; set `noise_device="cuda"` to 
 """
 import os
 import random
+import sys
 from copy import deepcopy
 
 import numpy as np
@@ -385,7 +386,7 @@ class FreeFinePipeline:
                     if not FreeFinePipeline._warned_ref_cache:
                         FreeFinePipeline._warned_ref_cache = True
                         print(f"[freefine_amd] reference-stream record of {per_step * n_rec / 2**30:.1f} GiB exceeds ref_cache_max_bytes "
-                              f"({self.ref_cache_max_bytes / 2**30:.1f} GiB): recomputing the reference rows instead", flush=True)
+                              f"({self.ref_cache_max_bytes / 2**30:.1f} GiB): recomputing the reference rows instead", file=sys.stderr, flush=True)
                     cache = None
             if guidance_scale > 1.:
                 eu, ec = noise_pred.chunk(2, dim=0)

@@ -418,6 +418,35 @@ def test_edit_at_768_px_vs_oracle(gpu):
     assert model._work_size(np.zeros((256, 256, 3), np.uint8)) == [512, 512]
 
 
+def test_full_size_edit_at_768_px_modes_agree(gpu):
+    """BASELINE configs[4] at ITS size: the SD-2.1-base UNet (865.9 M parameters) on a 768 x 768 edit (96 x 96 latents; TCA in blocks 10-15 at
+    S = 9216 / 2304, local cross-attention, masked CFG, eta = 1), N = 10 / start_step 7 (3 + 3 forwards), through the hipGraphs.  The CPU oracle
+    cannot run this (its modulated attention materialises [4 h, S, S] scores: 20 GB of host memory per call), so the gate is CROSS-MODE: the
+    split-bf16 mode against the fp32 mode -- itself pinned to the oracle per forward at this size (test_unet_full_size_768px_latent_96x96), per
+    kernel at S = 9216 (test_attention_tca_production_shapes) and end to end at 64 x 64 (G10) -- at <= 1e-3 ABSOLUTE latent L-inf."""
+    from golden_cases import rect_mask
+    from oracle import sd_unet
+    H, k = 768, 6
+    rng = np.random.default_rng(0)
+    ori_img, coarse = rng.integers(0, 256, (H, H, 3), dtype=np.uint8), rng.integers(0, 256, (H, H, 3), dtype=np.uint8)
+    ori, tgt, draw = rect_mask(H, H, 50 * k, 76 * k, 24 * k, 50 * k, 255), rect_mask(H, H, 50 * k, 76 * k, 40 * k, 66 * k, 255), rect_mask(H, H, 46 * k, 80 * k, 36 * k, 72 * k, 1)
+    kw = dict(end_step=10, num_step=10, start_step=7, method_type="tca", end_scale=0.0, draw_mask=draw)
+    ust = sd_unet.init_unet(sd_unet.unet_config("sd21-base"), seed=0).state_dict()
+    trajs = {}
+    for name, dtype, x3 in (("fp32", torch.float32, False), ("split-bf16", torch.float32, True), ("bf16", torch.bfloat16, False)):
+        model = make_pipe(gpu, "sd21-base", "edit", dtype=dtype, graph=True, ustate=ust, x3=x3)
+        img = model.FreeFine_generation(ori_img, ori, coarse, tgt, "a photo of a cup", 7.5, 1.0, verbose=True, seed=42, return_intermediates=True, **kw)
+        assert img.shape == (H, H, 3) and model.last_intermediates[0].shape[-2:] == (96, 96)
+        trajs[name] = torch.stack([t.detach().float().cpu() for t in model.last_intermediates])
+        del model
+        torch.cuda.empty_cache()
+    assert torch.isfinite(trajs["fp32"]).all()
+    d3 = (trajs["split-bf16"] - trajs["fp32"]).abs().max().item()
+    d16 = (trajs["bf16"] - trajs["fp32"]).abs().max().item()
+    print(f"full-size 768 x 768 edit (3 + 3 forwards, |latent| max {trajs['fp32'].abs().max():.2f}): split-bf16 vs fp32 {d3:.2e}, bf16 vs fp32 {d16:.2e}")
+    assert d3 < TOL
+
+
 from golden_cases import oracle_pipe  # noqa: E402
 
 

@@ -11,6 +11,14 @@ python3 $R/bench.py $F --tune-file /tmp/ffn_tune_r4.pt > /dev/null 2>&1
 FFN_IGEMM_TUNE_FILE=/tmp/ffn_tune_r4.pt rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r4 -- python3 $R/bench.py $F > $R/gpurun_out/r4_bench_prof_c1.json 2> $R/gpurun_out/r4_bench_prof_c1.err
 cp "$(ls /tmp/prof_r4/*/*kernel_stats.csv | head -1)" $R/gpurun_out/r4_kernel_stats_1stream.csv
 cp $R/gpurun_out/bench_kernel_table.txt $R/gpurun_out/r4_bench_event_table_1stream.txt
+# the same with every launch EAGER (--no-graph): graph-replayed launches run back to back and are faster than event-bracketed eager ones (small kernels by
+# up to 15 %), so only this run's rocprofv3 averages are like-for-like with the event-timed roofline leg of the same process
+rm -rf /tmp/prof_r4e
+cd /tmp
+FFN_IGEMM_TUNE_FILE=/tmp/ffn_tune_r4.pt rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r4e -- python3 $R/bench.py $F --no-graph > $R/gpurun_out/r4_bench_prof_c1_eager.json 2> $R/gpurun_out/r4_bench_prof_c1_eager.err
+cp "$(ls /tmp/prof_r4e/*/*kernel_stats.csv | head -1)" $R/gpurun_out/r4_kernel_stats_1stream_eager.csv
+cp $R/gpurun_out/bench_kernel_table.txt $R/gpurun_out/r4_bench_event_table_1stream_eager.txt
+cd $R
 cd $R
 ONE_MODE=x3 ONE_B=16 bash tools/pmc.sh r4_x3_conv_64x64_320_16rows conv 64 320 320 > /dev/null
 ONE_MODE=x3 ONE_B=24 bash tools/pmc.sh r4_x3_conv_64x64_320_24rows conv 64 320 320 > /dev/null
