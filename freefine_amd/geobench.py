@@ -108,8 +108,8 @@ def load_case_3d_rgb(case, dst_base, dsize=(512, 512), depth_model=None, focal_l
     """a GeoBench-3D case whose coarse edit is built HERE from the RGB image and its 3-D transform instead of being read from disk
     (freefine_batch_infer_3d_depth.py:121 reads coarse3d_depth_anything/...png, which evaluation/FreeFine/get_3d_transform_correspondence.py
     rendered beforehand): DepthAnything depth -> point-cloud warp of the object's pixels (freefine_amd.warp3d, geo_utils.py:427-528) over the
-    inpainted background.  edit_param = [tx, ty, tz (pixels at the 512 reference size), rx, ry, rz (degrees), sx, sy, sz] (:235-247); the
-    translation is passed relative to the image size, as the reference does (edit_param / LENGTH)."""
+    inpainted background.  edit_param = [tx, ty, tz (pixels at the 512 reference size), rx, ry, rz (degrees), sx, sy, sz]
+    (get_3d_transform_correspondence.py:235-247); the object moves by that many pixels at its mean depth (warp3d pixel_translation)."""
     from . import warp3d
     assert depth_model is not None, "the 3d_rgb variant needs a depth model (freefine_amd.depth.HipDepthAnything or depth_anything.dpt.DepthAnything)"
     ori_img = read_and_resize_img(case["ori_img_path"], dsize)
@@ -117,7 +117,8 @@ def load_case_3d_rgb(case, dst_base, dsize=(512, 512), depth_model=None, focal_l
     bg = read_and_resize_img(osp.join(dst_base, INP_SUBDIR, str(case["da_n"]), str(case["ins_id"]), "inp_img.png"), dsize)
     depth = monocular_depth(ori_img, depth_model)
     ep = [float(v) for v in case["edit_param"]]
-    tf = [ep[0] / 512.0, ep[1] / 512.0, ep[2] / 512.0, ep[3], ep[4], ep[5], ep[6], ep[7], ep[8]]
+    sc = dsize[0] / 512.0                                    # edit_param translations are pixels at the 512 reference size
+    tf = [ep[0] * sc, ep[1] * sc, ep[2] * sc, ep[3], ep[4], ep[5], ep[6], ep[7], ep[8]]
     m2 = ori_mask if ori_mask.ndim == 2 else ori_mask[:, :, 0]
     coarse, target_mask = warp3d.coarse_edit_3d(ori_img, m2, depth, tf, bg, focal_length=focal_length * dsize[0] / 512.0)
     draw = ndimage_max(np.maximum(target_mask, (m2 > 0).astype(np.uint8) * 255), 9)

@@ -34,10 +34,12 @@ def euler_xyz_matrix(rx, ry, rz):
 
 
 def point_cloud_warp(img, depth, transforms, focal_length_x, focal_length_y, mask, object_only=True, splatting_radius=0.1,
-                     splatting_points_per_pixel=5, device="cuda:0", fov_deg=60.0, return_covered=False):
+                     splatting_points_per_pixel=5, device="cuda:0", fov_deg=60.0, return_covered=False, pixel_translation=False):
     """img uint8 [H, W, 3], depth float [H, W], mask [H, W] (> 0 = object), transforms = [tx, ty, tz (relative to the cloud's extent),
     rx, ry, rz (degrees), sx, sy, sz] -> (rendered uint8 [H, W, 3], mask uint8 [H, W] by the reference's own test `sum of the K ids != -30`
-    -- 255 everywhere unless K = 30, geo_utils.py:517) and, with return_covered, the pixels any point reached (x 255)."""
+    -- 255 everywhere unless K = 30, geo_utils.py:517) and, with return_covered, the pixels any point reached (x 255).
+    pixel_translation (extension, off = the reference's semantics): tx, ty, tz are IMAGE PIXELS -- the cloud moves by t * mean depth / focal
+    length, i.e. by t pixels to the right / down at its mean depth (tz: away from the camera) -- instead of fractions of the cloud's extent."""
     lib = L.load()
     dev = torch.device(device)
     H, W = depth.shape
@@ -62,7 +64,10 @@ def point_cloud_warp(img, depth, transforms, focal_length_x, focal_length_y, mas
         for a in range(3):
             x.center[a] = float(c_h[a])
             t = float(transforms[a])
-            x.translate[a] = 0.0 if t == 0 else float(ext[a]) * t          # refine_transforms (geo_utils.py:399-413)
+            if pixel_translation:                                          # world +x / +y point left / up after the flip of geo_utils.py:455
+                x.translate[a] = (-1.0 if a < 2 else 1.0) * t * float(c_h[2]) / float((focal_length_x, focal_length_y, focal_length_x)[a])
+            else:
+                x.translate[a] = 0.0 if t == 0 else float(ext[a]) * t      # refine_transforms (geo_utils.py:399-413)
             x.scale[a] = float(transforms[6 + a])
         R = euler_xyz_matrix(*transforms[3:6])
         for a in range(9):
@@ -89,15 +94,17 @@ def point_cloud_warp(img, depth, transforms, focal_length_x, focal_length_y, mas
 
 
 def coarse_edit_3d(ori_img, ori_mask, depth, transforms, background, focal_length=550.0, splatting_radius=None, points_per_pixel=5,
-                   device="cuda:0"):
+                   device="cuda:0", pixel_translation=True):
     """The coarse 3-D edit a GeoBench-3D case starts from, built from the RGB image and its transform instead of being read from disk
     (freefine_batch_infer_3d_depth.py:121 reads `coarse3d_depth_anything/...png`): the object's pixels, lifted through `depth`, moved by
-    `transforms` and splatted over `background` (the inpainted scene).  Returns (coarse uint8 [H, W, 3], target_mask uint8 {0, 255}).
+    `transforms` (translation in image pixels by default: GeoBench's edit_param convention) and splatted over `background` (the inpainted
+    scene).  Returns (coarse uint8 [H, W, 3], target_mask uint8 {0, 255}).
     Default radius: 1.5 pixels in NDC units (holes between neighbouring source pixels close under moderate rotations / scalings)."""
     H, W = ori_mask.shape[:2]
     m2 = ori_mask if ori_mask.ndim == 2 else ori_mask[:, :, 0]
     r = splatting_radius if splatting_radius is not None else 1.5 * 2.0 / min(H, W)
-    img, _, cov = point_cloud_warp(ori_img, depth, transforms, focal_length, focal_length, m2, True, r, points_per_pixel, device, return_covered=True)
+    img, _, cov = point_cloud_warp(ori_img, depth, transforms, focal_length, focal_length, m2, True, r, points_per_pixel, device, return_covered=True,
+                                   pixel_translation=pixel_translation)
     tgt = cov > 0
     coarse = np.where(tgt[:, :, None], img, background).astype(np.uint8)
     return coarse, tgt.astype(np.uint8) * 255

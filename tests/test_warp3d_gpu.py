@@ -60,6 +60,10 @@ def test_point_cloud_warp_invariants_and_repeatability(gpu):
     out, _, cov = warp3d.point_cloud_warp(img, depth, [-5 / ext, 0, 0, 0, 0, 0, 1, 1, 1], f, f, mask, True, r, 5, device=gpu, return_covered=True)
     assert np.array_equal(cov, np.roll(cov0, 5, axis=1))
     assert np.abs(out.astype(int) - np.roll(base, 5, axis=1).astype(int)).max() <= 1
+    # translation given in image pixels (the GeoBench edit_param convention of the 3d_rgb variant): +7 px right, +3 px down at constant depth
+    outp, _, covp = warp3d.point_cloud_warp(img, depth, [7, 3, 0, 0, 0, 0, 1, 1, 1], f, f, mask, True, r, 5, device=gpu, return_covered=True, pixel_translation=True)
+    assert np.array_equal(covp, np.roll(cov0, (3, 7), axis=(0, 1)))
+    assert np.abs(outp.astype(int) - np.roll(base, (3, 7), axis=(0, 1)).astype(int)).max() <= 1
     big = [0.1, 0.1, 0, 15, -30, 20, 1.1, 0.9, 1.0]
     a = warp3d.point_cloud_warp(img, 2.0 + 0 * depth, big, f, f, mask, True, 4.0 * 2 / w, 15, device=gpu)     # constant depth: every depth ties
     b = warp3d.point_cloud_warp(img, 2.0 + 0 * depth, big, f, f, mask, True, 4.0 * 2 / w, 15, device=gpu)

@@ -1,5 +1,5 @@
 """Timings of the other task-level entry points at full size (GPU box): background generation (GeoBench bg-gen schedule) and
-cross-image composition with R=2 references.  python tools/bench_other.py"""
+cross-image composition with R=2 references.  python tools/bench_other.py [--dtype bf16x3|bf16|f32]"""
 import argparse
 import os
 import sys
@@ -12,7 +12,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from freefine_amd.attention import Attention_Modulator, register_attention_control_4bggen, register_attention_control_compose  # noqa: E402
 
-args = argparse.Namespace(model="sd21-base", vae="sd", dtype="bf16", no_graph=False, no_dedup=False, num_step=50, start_step=0, batch=1)
+ap = argparse.ArgumentParser()
+ap.add_argument("--dtype", default="bf16x3", choices=["bf16", "f32", "bf16x3"])
+cli = ap.parse_args()
+args = argparse.Namespace(model="sd21-base", vae="sd", dtype=cli.dtype, no_graph=False, no_dedup=False, num_step=50, start_step=0, batch=1, planted=3.0,
+                          text="clip", fp8_conv=False)
+print(f"mode {cli.dtype}; planted-denoiser synthetic weights; real-size CLIP-shaped text encoder (prompt cache on)")
 dev = torch.device("cuda:0")
 model = bench.build_model(args, dev, 0, 1)
 ori_img, ori_mask, coarse, tgt_mask, draw = bench.synth_inputs(0)
