@@ -92,7 +92,8 @@ def build_model(args, device, rank, world):
 
     def unet_state():       # seeded default-init tensors + the planted denoiser path (O(1) latents over the 50-step schedule, see weights.py)
         st = synthetic_state(unet_param_shapes(ucfg), 0)
-        return plant_denoiser_path(st, ucfg, args.planted) if args.planted > 0 else st
+        planted = getattr(args, "planted", 0.0)          # (tools/* build models through this function with their own argument sets)
+        return plant_denoiser_path(st, ucfg, planted) if planted > 0 else st
     if world > 1:
         from freefine_amd import dist as FD
         # rank 0 generates (stands for: reads) the weights, the others receive them over RCCL straight into device memory; bf16 payload
@@ -104,7 +105,7 @@ def build_model(args, device, rank, world):
         ust, vst = unet_state(), synthetic_state(vae_param_shapes(vcfg), 1)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     global _TEXT_ENCODER
-    if args.text == "clip":
+    if getattr(args, "text", "table") == "clip":
         if _TEXT_ENCODER is None:       # seeded: identical on every rank; shared by every mode built in this process
             _TEXT_ENCODER = clip_shaped_text_encoder(ucfg.cross_attention_dim).to(device)
         enc = _TEXT_ENCODER
