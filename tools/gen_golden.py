@@ -667,8 +667,55 @@ def run_g9(A, Mo):
         print(f"[G9] {r[0]:14s} {r[1]:2d} guided steps: oracle vs reference ABSOLUTE latent deviation {r[2]:.3e} (|latent| max {r[3]:.2f}), uint8 image max diff {r[4]}")
 
 
+# --------------------------------------------------------------------------------------------------------------
+# G11: the model-free arithmetic of the metric suite (evaluation/metrics): warp error, Frechet distance, polynomial MMD^2
+# --------------------------------------------------------------------------------------------------------------
+def run_g11():
+    import tempfile
+    import types
+    from PIL import Image
+    mroot = os.path.join(RH.REF, "evaluation", "metrics")
+    if mroot not in sys.path:
+        sys.path.insert(0, mroot)
+    for name in ("torchvision", "torchvision.transforms", "pytorch_fid", "pytorch_fid.inception"):      # imported by fid_score.py, unused by the function taken from it
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["pytorch_fid.inception"].InceptionV3 = type("InceptionV3", (), {"BLOCK_INDEX_BY_DIM": {2048: 3}})
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    from FID.fid_score import calculate_frechet_distance
+    from FID.mmd import compute_mmd, compute_polynomial_mmd
+    import wrap_error as WE
+    out = {}
+    rng = np.random.default_rng(11)
+    f1, f2 = rng.standard_normal((300, 24)), rng.standard_normal((260, 24)) * 1.3 + 0.2
+    out["feat_a"], out["feat_b"] = f1, f2
+    mu1, s1, mu2, s2 = f1.mean(0), np.cov(f1, rowvar=False), f2.mean(0), np.cov(f2, rowvar=False)
+    out["frechet"] = np.array([calculate_frechet_distance(mu1, s1, mu2, s2), calculate_frechet_distance(mu1, s1, mu1, s1)])
+    out["mmd2"] = np.array([compute_polynomial_mmd(f1[:200], f2[:200]), compute_polynomial_mmd(f1[:64], f1[64:128])])
+    np.random.seed(5)
+    out["kd"] = compute_mmd(f1, f2, n_subsets=7, subset_size=100)
+    with tempfile.TemporaryDirectory() as td:
+        data, k = {}, 0
+        for d in range(2):
+            inst = {}
+            for e in range(2):
+                paths = {}
+                for nm, arr in (("coarse_input_path", rng.integers(0, 256, (40, 48, 3), dtype=np.uint8)), ("gen", rng.integers(0, 256, (40, 48, 3), dtype=np.uint8)),
+                                ("tgt_mask_path", (rng.random((40, 48)) > 0.6).astype(np.uint8) * 255)):
+                    fp = os.path.join(td, f"{k}_{nm}.png")
+                    Image.fromarray(arr).save(fp)
+                    paths[nm] = fp
+                    out[f"we_{k}_{nm}"] = arr
+                inst[str(e)] = paths
+                k += 1
+            data[str(d)] = {"instances": {"0": inst}}
+        out["we"] = np.array([WE.calculate_we(data, "gen")])
+    np.savez_compressed(os.path.join(GOLD, "g11_metrics.npz"), **out)
+    print(f"[G11] frechet {out['frechet']}, mmd2 {out['mmd2']}, kd mean {out['kd'].mean():.6f}, warp error {out['we'][0]:.6f}")
+
+
 if __name__ == "__main__":
-    only = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g9"]
+    only = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g9", "g11"]
     torch.set_grad_enabled(False)
     A, Mo = RH.import_reference()
     if "g1" in only:
@@ -689,3 +736,5 @@ if __name__ == "__main__":
         run_g8()
     if "g9" in only:
         run_g9(A, Mo)
+    if "g11" in only:
+        run_g11()
