@@ -338,7 +338,7 @@ def main():
                     help="arithmetic mode of the timed region; default = the fastest mode that holds the 1e-3 latent tolerance on the N=50 fixtures")
     ap.add_argument("--planted", type=float, default=3.0, help="gain of the planted denoiser path of the synthetic UNet weights (0 = purely random weights)")
     ap.add_argument("--text", default="clip", choices=["clip", "table"], help="text encoder inside the timed region: real-size CLIP-shaped transformers model "
-                    "on the device (prompt cache off) or the table-lookup stand-in of the tests")
+                    "on the device (one prompt per call, cache emptied before every batch of edits) or the table-lookup stand-in of the tests")
     ap.add_argument("--extra-steps", dest="extra_steps", type=int, default=3, help="timed steps of the f32 / fast-mode legs")
     ap.add_argument("--model", default="sd21-base")
     ap.add_argument("--vae", default="sd")
@@ -358,6 +358,7 @@ def main():
     ap.add_argument("--fp8-conv", dest="fp8_conv", action="store_true", help="bf16 mode with e4m3 ResBlock convolutions (FFN_FP8) as the timed configuration")
     ap.add_argument("--fp8-leg", dest="fp8_leg", action="store_true", help="also measure the bf16 + e4m3-convolution variant under fast_modes (it bought "
                     "nothing in the round-3 driver run, so it is off the default line)")
+    ap.add_argument("--no-fp8-leg", dest="no_fp8_leg", action="store_true", help="accepted and ignored (round-3 profiling scripts): the fp8 leg is opt-in now")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity leg (f32 trajectory + throughput, the headline mode's latent deviation)")
     ap.add_argument("--no-fast-modes", dest="no_fast_modes", action="store_true", help="skip the bf16 fast-mode leg")
     args = ap.parse_args()
