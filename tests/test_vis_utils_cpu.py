@@ -137,3 +137,28 @@ def test_geobench_harness_world2_gloo(tmp_path):
     # second run: everything exists already -> nothing to do, JSON rebuilt from the existing results
     cl = geobench.CaseList(V.load_json(os.path.join(root, "annotations_2d.json")), os.path.join(root, geobench.GEN_SUBDIR))
     assert len(cl) == 0 and len(cl.existing_results) == n
+
+
+def test_monocular_depth_wrapper_around_a_depth_network():
+    """geobench.monocular_depth (the reference's get_monocular_depth_anything: resize to a multiple of 14 with the shorter side at 518, ImageNet
+    normalisation, network, bilinear back, max - d, push-back) around a stand-in network that returns the normalised red channel"""
+    import numpy as np
+    import torch
+    from freefine_amd import geobench
+
+    seen = {}
+
+    class Net:
+        device = "cpu"
+
+        def __call__(self, x):
+            seen["shape"] = tuple(x.shape)
+            return x[:, 0] * 0.229 + 0.485                      # undo the normalisation of channel 0: the image's red channel in [0, 1]
+
+    img = np.zeros((60, 90, 3), np.uint8)
+    img[:, :, 0] = np.linspace(0, 255, 90).astype(np.uint8)[None, :]     # red ramps left -> right: "disparity" grows to the right
+    d = geobench.monocular_depth(img, Net(), translate_factor=0.1)
+    assert seen["shape"][0] == 1 and seen["shape"][1] == 3 and seen["shape"][2] % 14 == 0 and seen["shape"][3] % 14 == 0
+    assert min(seen["shape"][2:]) in (518 // 14 * 14, 518) and d.shape == (60, 90) and d.dtype == np.float32
+    assert (np.diff(d.mean(0)) <= 1e-4).all()                   # depth = max - disparity: falls to the right
+    assert d.min() > 0 and abs(d.min() - 0.1 * (d.max() - d.min()) / 1.0) < 0.02      # pushed back by translate_factor * max(depth before the push)
