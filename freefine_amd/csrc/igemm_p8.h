@@ -345,6 +345,25 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         // residual: all loads of the half tile first (their registers are the half's own, dead, accumulators' worth), ONE wait, then
         // the sums -- hipcc waits vmcnt(0) at the first use of a register-destination load while LDS-DMA loads are in flight, so a
         // load-use pair per fragment row would drain the K-tile stream once per row
+        if constexpr (RES && X3) {
+            // fp32 residual (16 bytes per lane and fragment): loaded STRAIGHT INTO the half tile's own, dead, accumulators -- no staging registers at
+            // all -- with one wait for the whole half, then bias + row bias are added in place.  (Round 4: the staged form, one fragment row per
+            // batch, still made hipcc spill 24-138 registers per lane in the RES x X3 instantiations and drained the K-tile stream four times per half.)
+            const int voff = (l15 * p.ldr + 4 * g) * 4;
+#pragma unroll
+            for (int i = i0; i < i0 + FH; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcR, voff, ((m0 + i * 16) * p.ldr + n0 + j * 16) * 4, 0));
+#pragma unroll
+            for (int i = i0; i < i0 + FH; ++i) {
+                const int rb_off = (i * 16 + l15 >= E) ? 1024 : 512;
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] += *reinterpret_cast<const f32x4*>(slot + (j * 16 + 4 * g) * 4) + *reinterpret_cast<const f32x4*>(slot + rb_off + (j * 16 + 4 * g) * 4);
+            }
+            return;
+        }
         constexpr int RB = X3 ? 1 : ((BM == 256 && BN == 320) ? 2 : FH);      // fragment rows per batch (register budget of the largest tile)
 #pragma unroll
         for (int ib = i0; ib < i0 + FH; ib += RB) {
