@@ -1,6 +1,7 @@
 """bench.py -- the FreeFine hot path on MI355X, measured on BASELINE.json's metric and config.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W        (N>1: one rank per GPU over RCCL -- either started by torch.distributed.run, or, when
+                                                          no rank environment is set, bench.py starts the N ranks itself as child processes)
 
 One "step" = one pass of the hot path over one batch of synthetic inputs = `--concurrent` x `--batch` full `FreeFine_generation`
 edits at 512x512 on SD-2.1-base topology (865.9 M parameter UNet + SD VAE, seeded synthetic weights: no checkpoints exist
@@ -327,9 +328,27 @@ def cpu_baseline_leg(args):
                        f"VAE encode+decode @512^2 once x2 ({t_vae:.2f}s); torch fp32, {cores} threads")
 
 
+def launch_command(n, argv, port=None):
+    """`python bench.py --gpus N` without a rank environment: the command line of the N-rank job (one process per GPU over RCCL,
+    rendezvous on 127.0.0.1) -- what the reference's run_script_2D.sh:12-14 does with `torchrun --nproc_per_node=8`."""
+    port = port or int(os.environ.get("MASTER_PORT", 0)) or (29500 + os.getpid() % 2000)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_launch_ranks(args, argv, environ=os.environ):
+    """--gpus N > 1 outside a torch.distributed.run job: start the N rank processes as CHILDREN (this parent has not touched the GPU and
+    never will), relay their output -- rank 0 prints the JSON line -- and return the job's exit code; None when this process is itself a
+    rank (WORLD_SIZE set: the driver's own `torch.distributed.run ... bench.py --gpus N` form, and our children) or N == 1."""
+    if args.gpus <= 1 or "WORLD_SIZE" in environ:
+        return None
+    import subprocess
+    return subprocess.run(launch_command(args.gpus, argv), env=dict(environ)).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks (one per GPU); > 1 without a rank environment starts them through torch.distributed.run")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tune-file", default=os.environ.get("FFN_IGEMM_TUNE_FILE", ""),
@@ -362,6 +381,9 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the parity leg (f32 trajectory + throughput, the headline mode's latent deviation)")
     ap.add_argument("--no-fast-modes", dest="no_fast_modes", action="store_true", help="skip the bf16 fast-mode leg")
     args = ap.parse_args()
+    rc = maybe_launch_ranks(args, sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     # smoke-testing the multi-rank path on a 1-GPU box: FFN_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0 and uses gloo (RCCL refuses

@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--base-dir", required=True)
     ap.add_argument("--model", default="synthetic:sd21-base")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--dtype", default="bf16x3", choices=["bf16x3", "f32", "bf16"], help="bf16x3 = split-bf16 (default, bench.py's headline mode), f32 = parity mode, bf16 = fast mode")
     ap.add_argument("--no-blending", action="store_true")
     ap.add_argument("--bench", default="2D", choices=["2D", "3D"])
     ap.add_argument("--batch", type=int, default=4, help="cases processed together in one UNet batch")
@@ -29,7 +29,7 @@ def main():
     device = torch.device(f"cuda:{local}")
     if world > 1:
         torch.distributed.init_process_group("nccl", device_id=device)
-    model = FreeFinePipeline.from_pretrained(args.model, torch_dtype=torch.float32 if args.dtype == "f32" else torch.bfloat16, device=device, broadcast="auto").to(device)
+    model = FreeFinePipeline.from_pretrained(args.model, torch_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, device=device, broadcast="auto", x3=args.dtype == "bf16x3").to(device)
     model._progress_bar_config = {"disable": True}
     model.scheduler = DDIMScheduler.from_config(model.scheduler.config)
     controller = Attention_Modulator(start_layer=10)

@@ -82,11 +82,13 @@ def load_case_3d_depth(case, dst_base, dsize=(512, 512)):
                 draw_mask=read_and_resize_mask(case["draw_mask"], dsize), use_auto_draw=False, reduce_inp_artifacts=True, cons_area=target_mask)
 
 
-def monocular_depth(img, depth_model, translate_factor=0.1, side=518):
-    """get_monocular_depth_anything (the reference's callers: evaluation/DiffusionHandles/eval_geobench.py:163-215, src/utils/ui_utils.py:380-401):
+def monocular_depth(img, depth_model, translate_factor=0.0, side=518):
+    """get_monocular_depth_anything as src/utils/ui_utils.py:380-402 calls it (`get_depth(..., translate_factor=0.0)`; the copy in
+    evaluation/DiffusionHandles/eval_geobench.py:163-215 has its push-back line commented out, :214):
     shorter side -> `side` (a multiple of 14, aspect kept, both sides multiples of 14), ImageNet normalisation, the depth network, bilinear back
-    to the image size, `depth.max() - depth` (relative -> absolute), pushed back by translate_factor * max so that no point sits at z = 0.
-    The resampling around the network is torch (plumbing); the network is freefine_amd.depth.HipDepthAnything."""
+    to the image size, `depth.max() - depth` (relative -> absolute), pushed back by translate_factor * max (0 by default, like get_depth).
+    The resampling around the network is torch (plumbing); the network is freefine_amd.depth.HipDepthAnything.  Runs on the CALLER's thread
+    and current device (geobench.run calls it on the consumer thread, never on the prefetch thread)."""
     import torch
     import torch.nn.functional as F
     h, w = img.shape[:2]
@@ -104,27 +106,42 @@ def monocular_depth(img, depth_model, translate_factor=0.1, side=518):
     return d.clamp_min(0).cpu().numpy().astype(np.float32)
 
 
-def load_case_3d_rgb(case, dst_base, dsize=(512, 512), depth_model=None, focal_length=550.0):
-    """a GeoBench-3D case whose coarse edit is built HERE from the RGB image and its 3-D transform instead of being read from disk
-    (freefine_batch_infer_3d_depth.py:121 reads coarse3d_depth_anything/...png, which evaluation/FreeFine/get_3d_transform_correspondence.py
-    rendered beforehand): DepthAnything depth -> point-cloud warp of the object's pixels (freefine_amd.warp3d, geo_utils.py:427-528) over the
-    inpainted background.  edit_param = [tx, ty, tz (pixels at the 512 reference size), rx, ry, rz (degrees), sx, sy, sz]
-    (get_3d_transform_correspondence.py:235-247); the object moves by that many pixels at its mean depth (warp3d pixel_translation)."""
+def read_case_3d_rgb(case, dst_base, dsize=(512, 512)):
+    """HOST half of the 3d_rgb loader (files only: safe on the prefetch thread): image, mask, inpainted background, edit parameters"""
+    return dict(_raw_3d_rgb=True, ori_img=read_and_resize_img(case["ori_img_path"], dsize), ori_mask=read_and_resize_mask(case["ori_mask_path"], dsize),
+                bg=read_and_resize_img(osp.join(dst_base, INP_SUBDIR, str(case["da_n"]), str(case["ins_id"]), "inp_img.png"), dsize),
+                edit_param=[float(v) for v in case["edit_param"]], obj_label=case.get("obj_label", ""), dsize=tuple(dsize))
+
+
+def finish_case_3d_rgb(raw, depth_model, focal_length=550.0):
+    """DEVICE half of the 3d_rgb loader (depth network + point-cloud warp on the HIP kernels): call it on the thread that owns the device
+    and the stream -- geobench.run does so on its consumer thread, between batches, never concurrently with a graph capture."""
     from . import warp3d
     assert depth_model is not None, "the 3d_rgb variant needs a depth model (freefine_amd.depth.HipDepthAnything or depth_anything.dpt.DepthAnything)"
-    ori_img = read_and_resize_img(case["ori_img_path"], dsize)
-    ori_mask = read_and_resize_mask(case["ori_mask_path"], dsize)
-    bg = read_and_resize_img(osp.join(dst_base, INP_SUBDIR, str(case["da_n"]), str(case["ins_id"]), "inp_img.png"), dsize)
-    depth = monocular_depth(ori_img, depth_model)
-    ep = [float(v) for v in case["edit_param"]]
+    ori_img, ori_mask, bg, dsize = raw["ori_img"], raw["ori_mask"], raw["bg"], raw["dsize"]
+    depth = monocular_depth(ori_img, depth_model, translate_factor=0.1)      # this variant's own choice: no point of the cloud at z = 0
+    ep = raw["edit_param"]
     sc = dsize[0] / 512.0                                    # edit_param translations are pixels at the 512 reference size
     tf = [ep[0] * sc, ep[1] * sc, ep[2] * sc, ep[3], ep[4], ep[5], ep[6], ep[7], ep[8]]
     m2 = ori_mask if ori_mask.ndim == 2 else ori_mask[:, :, 0]
     coarse, target_mask = warp3d.coarse_edit_3d(ori_img, m2, depth, tf, bg, focal_length=focal_length * dsize[0] / 512.0)
     draw = ndimage_max(np.maximum(target_mask, (m2 > 0).astype(np.uint8) * 255), 9)
-    return dict(ori_img=ori_img, ori_mask=ori_mask, coarse_input=coarse, target_mask=target_mask, guidance_text=case.get("obj_label", ""),
+    return dict(ori_img=ori_img, ori_mask=ori_mask, coarse_input=coarse, target_mask=target_mask, guidance_text=raw["obj_label"],
                 draw_mask=(draw > 0).astype(np.uint8), use_auto_draw=False, reduce_inp_artifacts=True,
                 cons_area=np.maximum(target_mask, (m2 > 0).astype(np.uint8) * 255))
+
+
+def load_case_3d_rgb(case, dst_base, dsize=(512, 512), depth_model=None, focal_length=550.0):
+    """a GeoBench-3D case whose coarse edit is built HERE from the RGB image and a 3-D transform instead of being read from disk
+    (freefine_batch_infer_3d_depth.py:121 reads coarse3d_depth_anything/...png).  A NON-PARITY EXTENSION, not a restatement of the dataset's
+    generator: evaluation/FreeFine/get_3d_transform_correspondence.py:217-251 renders those files through the GeoDiffuser warp
+    (`get_transformed_mask`: translation edit_param / 512 in world units composed as T.S.Rx.Ry.Rz, splatting radius 1.3, 15 points per
+    pixel, depth from get_depth(translate_factor=0.0)), whose modules are not in the reference tree; here the cloud goes through
+    freefine_amd.warp3d (the pytorch3d splat of geo_utils.py:427-528: radius 1.5 px, K = 5), the translation is read as PIXELS at the 512
+    reference size at the object's mean depth (warp3d pixel_translation) and the depth is pushed back by 0.1 max.  Coarse images and target
+    masks therefore differ systematically from the dataset's coarse3d_depth_anything files; use --variant 3d_depth to reproduce those.
+    edit_param = [tx, ty, tz, rx, ry, rz (degrees), sx, sy, sz].  = read_case_3d_rgb (host) + finish_case_3d_rgb (device)."""
+    return finish_case_3d_rgb(read_case_3d_rgb(case, dst_base, dsize), depth_model, focal_length)
 
 
 def _prefetch(cases, dst_base, depth, dsize, loader=None):
@@ -229,20 +246,28 @@ def run(model, dst_base, batch=4, params=None, rank=0, world=1, check_exist=True
             results.append(dict(c, gen_img_path=path, key=f'{c["da_n"]}/{c["ins_id"]}/{c["edit_ins"]}'))
         pending.clear()
 
-    loader = {"2d": load_case, "3d_depth": load_case_3d_depth,
-              "3d_rgb": lambda c, b, d: load_case_3d_rgb(c, b, d, depth_model=depth_model)}[variant]
-    for case, inputs, err in _prefetch(mine, dst_base, 2 * batch, dsize, loader):
-        if err is not None:
-            if verbose:
-                print(f'[geobench] skipped {case["da_n"]}/{case["ins_id"]}/{case["edit_ins"]}: {err}')
-            continue
-        pending.append((case, inputs))
-        if len(pending) == batch:
-            flush()
-    flush()
-    merged = FD.gather_results(results) if world > 1 else results
-    if world > 1:
-        FD.restore_tuning()          # the freeze of warm_and_sync ends with the sharded run (a later phase of this process may tune again)
+    # the prefetch thread is HOST-ONLY (file reads, resizes): a new Python thread starts on device 0 with its own current stream, and device
+    # work issued from it would also race the consumer's graph captures; the 3d_rgb variant's depth network + warp run HERE, per case
+    loader = {"2d": load_case, "3d_depth": load_case_3d_depth, "3d_rgb": read_case_3d_rgb}[variant]
+    try:
+        for case, inputs, err in _prefetch(mine, dst_base, 2 * batch, dsize, loader):
+            if err is None and inputs.get("_raw_3d_rgb"):
+                try:
+                    inputs = finish_case_3d_rgb(inputs, depth_model)
+                except Exception as e:  # noqa: BLE001 -- reported with the case attached, like a failed read
+                    err = e
+            if err is not None:
+                if verbose:
+                    print(f'[geobench] skipped {case["da_n"]}/{case["ins_id"]}/{case["edit_ins"]}: {err}')
+                continue
+            pending.append((case, inputs))
+            if len(pending) == batch:
+                flush()
+        flush()
+        merged = FD.gather_results(results) if world > 1 else results
+    finally:
+        if world > 1:
+            FD.restore_tuning()      # the freeze of warm_and_sync ends with the sharded run, also when it ends in an exception
     if rank == 0:
         final = list(cl.existing_results) + merged
         new_data = {}

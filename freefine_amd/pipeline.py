@@ -270,7 +270,10 @@ class FreeFinePipeline:
         prompts = list(prompts)
         cache = self._text_cache if self.text_cache else None
         missing = [q for q in dict.fromkeys(prompts) if cache is None or q not in cache]
-        fresh = {}
+        # the hits are taken out of the cache BEFORE anything is inserted or evicted (an eviction made room for this call's misses could
+        # otherwise remove a prompt of this very call that was counted as a hit) and re-inserted behind the misses: most recently used last
+        fresh = {q: cache.pop(q) for q in dict.fromkeys(prompts) if cache is not None and q in cache}
+        hits = list(fresh)
         if missing:
             enc = self.text_encoder
             if isinstance(enc, torch.nn.Module) and not self._text_on_device:
@@ -289,19 +292,12 @@ class FreeFinePipeline:
                 self.text_encoder_calls += 1
             for j, q in enumerate(missing):
                 fresh[q] = out[j]
-                if cache is not None:
-                    cache[q] = out[j]
-                    while len(cache) > self.text_cache_max:
-                        cache.pop(next(iter(cache)))
-        rows = []
-        for q in prompts:
-            if q in fresh:
-                rows.append(fresh[q])
-            else:
-                v = cache.pop(q)            # re-insert: most recently used last
-                cache[q] = v
-                rows.append(v)
-        return torch.stack(rows).contiguous()
+        if cache is not None:
+            for q in missing + hits:
+                cache[q] = fresh[q]
+            while len(cache) > self.text_cache_max:
+                cache.pop(next(iter(cache)))
+        return torch.stack([fresh[q] for q in prompts]).contiguous()
 
     @torch.no_grad()
     def get_text_embeddings(self, prompt):

@@ -129,3 +129,23 @@ def fullsize_cases():
         "fs_edit_n20": (3.0, dict(method_type="tca", draw_mask=draw, use_auto_draw=False, cons_area=None, reduce_inp_artifacts=False,
                                   end_step=20, num_step=20, start_step=0, end_scale=0.0, guidance_text="a photo of a cup", guidance_scale=7.5, eta=1.0)),
     }
+
+
+def fullsize_hook_cases():
+    """the other two hooks at full size on the metric's N = 50 schedules (name -> (hook, planted gain, kwargs)):
+    background generation at start_step 1 (freefine_batch_infer_bggen_2d.py:149,166-180: 49 + 49 forwards) and the
+    composition with R = 2 references at start_step 15 (Appearance_transfer.ipynb cell 5 / SURVEY 8d C4: 35 + 35 forwards)."""
+    return {
+        "fs_bg_s1": ("bggen", 3.0, dict(method_type="tca", end_step=35, num_step=50, start_step=1, end_scale=0.5)),
+        "fs_cmp_s15": ("compose", 0.0, dict(method_type="tca", appearance_transfer=True, dil_completion=False, end_step=50, num_step=50,
+                                            start_step=15, end_scale=0.5, dil_factor=9)),
+    }
+
+
+def fullsize_hook_inputs():
+    """inputs of fullsize_hook_cases: the 512^2 images of fullsize_inputs + a third image, two (source, target) mask pairs"""
+    H = 512
+    ori_img, coarse, img2 = synth_images(H, H)
+    ori, tgt = rect_mask(H, H, 200, 304, 96, 200, 255), rect_mask(H, H, 200, 304, 160, 264, 255)
+    ori2, tgt2 = rect_mask(H, H, 40, 160, 280, 440, 255), rect_mask(H, H, 336, 472, 240, 400, 255)
+    return ori_img, coarse, img2, [ori, ori2], [tgt, tgt2]

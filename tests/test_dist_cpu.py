@@ -76,3 +76,33 @@ def test_world2_gloo_broadcast_and_gather(tmp_path):
                           "--master-port", "29517", str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "DIST_OK 7" in out.stdout
+
+
+def test_bench_gpus_flag_launches_ranks(monkeypatch):
+    """`python bench.py --gpus N` (no rank environment) starts N ranks through torch.distributed.run as CHILD processes and relays their exit code;
+    a process that already is a rank (WORLD_SIZE set: the driver's own torchrun form, and the children) never re-launches; N = 1 never launches.
+    Reference: /root/reference/evaluation/FreeFine/run_script_2D.sh:12-14 (torchrun --nproc_per_node=8)."""
+    import argparse
+    import importlib.util
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "2", "--warmup", "1"], port=29611)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29611"
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+    calls = []
+
+    def fake_run(c, env=None, **kw):
+        calls.append((c, env))
+        return subprocess.CompletedProcess(c, 7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    ns = argparse.Namespace(gpus=4)
+    assert bench.maybe_launch_ranks(ns, ["--gpus", "4"], environ={"PATH": "x"}) == 7 and len(calls) == 1
+    assert "--nproc-per-node=4" in calls[0][0] and calls[0][1]["PATH"] == "x"
+    assert bench.maybe_launch_ranks(ns, ["--gpus", "4"], environ={"WORLD_SIZE": "4", "RANK": "1"}) is None and len(calls) == 1
+    assert bench.maybe_launch_ranks(argparse.Namespace(gpus=1), [], environ={}) is None and len(calls) == 1

@@ -182,20 +182,22 @@ def test_bf16_fast_mode_deviation_reported(gpu):
     assert dev < 0.5
 
 
-def test_geobench_harness_on_gpu(gpu, tmp_path):
+@pytest.mark.parametrize("x3", [False, True], ids=["f32", "bf16x3"])
+def test_geobench_harness_on_gpu(gpu, tmp_path, x3):
     """the GeoBench-2D harness (freefine_amd/geobench.py: case list, host pre-processing without cv2, batches of cases through
-    FreeFine_generation_batch, PNG + JSON results) end to end on a synthetic GeoBenchMeta tree; one case re-run directly."""
+    FreeFine_generation_batch, PNG + JSON results) end to end on a synthetic GeoBenchMeta tree; one case re-run directly.  In the f32 parity
+    mode and in the split-bf16 mode the drivers default to (evaluation/FreeFine/freefine_batch_infer_2d.py --dtype bf16x3 = bench.py's mode)."""
     from PIL import Image
     from freefine_amd import geobench
     root = str(tmp_path / "geo")
     geobench.make_synthetic_dataset(root, n_images=2, edits_per_image=2, size=128, seed=3, with_backgrounds=False)
     # stage 1: object removal writes the background images stage 2 pastes the moved object onto
-    bg_model = make_pipe(gpu, "tiny", "bggen", graph=True)
+    bg_model = make_pipe(gpu, "tiny", "bggen", graph=True, x3=x3)
     bgs = geobench.run_bggen(bg_model, root, blending=True, params=dict(num_step=10, start_step=1, end_step=6), dsize=(128, 128), seed=7,
                              verbose=False)
     assert len(bgs) == 2 and all(os.path.exists(b["inp_img_path"]) for b in bgs)
     assert geobench.run_bggen(bg_model, root, params=dict(num_step=10, start_step=1, end_step=6), dsize=(128, 128), seed=7, verbose=False) == []
-    model = make_pipe(gpu, "tiny", "edit", graph=True)
+    model = make_pipe(gpu, "tiny", "edit", graph=True, x3=x3)
     params = dict(num_step=10, start_step=7, end_step=10)
     res = geobench.run(model, root, batch=3, params=params, dsize=(128, 128), verbose=False)      # 4 cases: a batch of 3, then a single one
     assert len(res) == 4 and os.path.exists(os.path.join(root, "generated_results_freefine_2d.json"))
@@ -219,14 +221,21 @@ def test_geobench_harness_on_gpu(gpu, tmp_path):
     dcfg = FDp.depth_config("tiny")
     dmodel = FDp.HipDepthAnything(dcfg, FDp.synthetic_state(dcfg, seed=3), dtype=torch.float32, device=gpu)
     root4 = str(tmp_path / "geo3d_rgb")
-    geobench.make_synthetic_dataset(root4, n_images=1, edits_per_image=2, size=128, seed=6, with_3d=True, with_backgrounds=True)
+    geobench.make_synthetic_dataset(root4, n_images=2, edits_per_image=4, size=128, seed=6, with_3d=True, with_backgrounds=True)
     case = geobench.load_json(os.path.join(root4, "annotations.json"))["0000"]["instances"]["0"]["0"]
     inp = geobench.load_case_3d_rgb(dict(case, da_n="0000", ins_id="0", edit_ins="0"), root4, (128, 128), depth_model=dmodel)
     assert inp["coarse_input"].shape == (128, 128, 3) and inp["target_mask"].max() == 255 and 0 < (inp["target_mask"] > 0).mean() < 0.5
-    res4 = geobench.run(model, root4, batch=2, params=dict(num_step=10, start_step=3, end_step=10), dsize=(128, 128), verbose=False,
+    # 8 cases in batches of 2 on a FRESH pipeline (no forward graph of this schedule captured yet) at start_step 4: the prefetch thread (host
+    # only: file reads) runs ahead of the consumer while it captures graphs; depth network + warp run on the consumer thread
+    model4 = make_pipe(gpu, "tiny", "edit", graph=True, x3=x3)
+    res4 = geobench.run(model4, root4, batch=2, params=dict(num_step=10, start_step=4, end_step=10), dsize=(128, 128), verbose=False,
                         variant="3d_rgb", depth_model=dmodel)
-    assert len(res4) == 2 and os.path.exists(os.path.join(root4, "generated_results_freefine_depth_rgb.json"))
+    assert len(res4) == 8 and os.path.exists(os.path.join(root4, "generated_results_freefine_depth_rgb.json"))
     assert all(np.isfinite(np.asarray(Image.open(r["gen_img_path"])).astype(float)).all() for r in res4)
+    raw = geobench.read_case_3d_rgb(dict(case, da_n="0000", ins_id="0", edit_ins="0"), root4, (128, 128))
+    assert raw["_raw_3d_rgb"] and all(isinstance(raw[k], np.ndarray) for k in ("ori_img", "ori_mask", "bg"))      # host half: arrays only
+    again = geobench.finish_case_3d_rgb(raw, dmodel)
+    assert np.array_equal(again["coarse_input"], inp["coarse_input"]) and np.array_equal(again["target_mask"], inp["target_mask"])
 
 
 def test_image_batched_background_generation_matches_single(gpu):

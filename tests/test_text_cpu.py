@@ -26,6 +26,20 @@ def test_text_cache_returns_the_encoder_rows_in_request_order():
     assert torch.equal(p.get_text_embeddings(["a cup"]), want[:1]) and p.text_encoder_calls == 4
 
 
+def test_text_cache_eviction_never_drops_a_prompt_of_the_same_call():
+    """with a full cache a call that mixes an old prompt (a hit) with a new one must not evict the hit before its row is built"""
+    enc = SyntheticTextEncoder(64)
+    p = _pipe(enc)
+    p.text_cache_max = 2
+    tok = ByteTokenizer()
+    p._encode_text(["a", "b"])
+    got = p._encode_text(["a", "c"])                            # used to raise KeyError('a')
+    assert torch.equal(got, enc(tok(["a", "c"]).input_ids)[0])
+    assert list(p._text_cache) == ["c", "a"] and p.text_encoder_calls == 2      # "b" evicted; the hit re-inserted last (most recently used)
+    got = p._encode_text(["d", "a", "a", "e"])                  # more distinct prompts than the cache holds: rows still complete and in order
+    assert torch.equal(got, enc(tok(["d", "a", "a", "e"]).input_ids)[0]) and len(p._text_cache) == 2
+
+
 def test_clip_shaped_text_encoder_is_a_transformers_clip_text_model_of_the_checkpoints_shape():
     enc = clip_shaped_text_encoder(1024, layers=2)              # 2 of the 23 layers: shape check only (the bench builds all 23)
     assert enc.config.hidden_size == 1024 and enc.config.num_attention_heads == 16 and enc.config.intermediate_size == 4096

@@ -16,7 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from golden_cases import fullsize_cases, fullsize_inputs  # noqa: E402
+from golden_cases import fullsize_cases, fullsize_hook_cases, fullsize_hook_inputs, fullsize_inputs  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -39,7 +39,24 @@ def main():
     torch.set_num_threads(int(os.environ.get("FFN_THREADS", "8")))
     ori_img, coarse, ori, tgt, draw, cons_sup = fullsize_inputs()
     cases = fullsize_cases()
+    hook_cases = fullsize_hook_cases()
     for name in sys.argv[1:]:
+        if name in hook_cases:                     # background generation / composition: the other two hooks (round 5)
+            hook, planted, kw = hook_cases[name]
+            img0, coarse0, img2, oris, tgts = fullsize_hook_inputs()
+            op = fullsize_oracle(planted)
+            t0 = time.time()
+            if hook == "bggen":
+                from oracle.masks import dilate_mask
+                dil = dilate_mask(oris[0] // 255, 30)           # freefine_batch_infer_bggen_2d.py:149
+                img_e, traj = op.freefine_background_generation(img0, dil, "empty scene", 7.5, 1.0, seed=7, **kw)
+            else:
+                img_e, traj = op.freefine_compose([img0, img2], oris, tgts, coarse0, ["a cup", "a dog"], 7.5, 1.0, seed=11, **kw)
+            traj = torch.stack([(t if t.ndim == 3 else t[0]).float() for t in traj])      # [n + 1, 4, 64, 64]: the edited row
+            print(f"{name}: {time.time() - t0:.0f} s, {traj.shape[0]} latents, |latent| max per step "
+                  f"{[round(v, 2) for v in traj.abs().flatten(1).max(1).values.tolist()][::5]}", flush=True)
+            np.savez_compressed(os.path.join(GOLD, f"g10_fullsize_{name}.npz"), traj_edit=traj.numpy(), img=img_e[::4, ::4].copy())
+            continue
         planted, kw = cases[name]
         kw = dict(kw)
         text, gs, eta = kw.pop("guidance_text"), kw.pop("guidance_scale"), kw.pop("eta")
