@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const AttnParams p) {
     if (dup >= 0) nactive = 1;
     // output row q of batch row b, columns head * D + d .. + 3: fp32, or (out_pair) the bf16 pair form hi | lo at ldo / 2
     auto store_out = [&](int q, int d, const float* vv) {
-        if (p.out_pair) store_pair_row4(reinterpret_cast<bf16*>(p.out) + ((long)b * p.S + q) * p.ldo + head * D + d, p.ldo / 2, vv);
+        if (p.out_pair) store_pair_row4(reinterpret_cast<bf16*>(p.out) + ((long)b * p.S + q) * p.ldo, head * D + d, p.ldo / 2, vv);
         else store4(Og + ((long)b * p.S + q) * p.ldo + head * D + d, vv);
     };
     if (nactive == 0) {

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(512) void attn_x3p_kernel(const AttnParams p) {
     const int dup = att_duplicate_pass(p, b, head);      // a self-referencing row's second pass on a head the mask skips: folded into the first
     if (dup >= 0) nactive = 1;
     auto store_out = [&](int q, int d, const float* vv) {
-        if (p.out_pair) store_pair_row4(reinterpret_cast<bf16*>(p.out) + ((long)b * p.S + q) * p.ldo + head * D + d, p.ldo / 2, vv);
+        if (p.out_pair) store_pair_row4(reinterpret_cast<bf16*>(p.out) + ((long)b * p.S + q) * p.ldo, head * D + d, p.ldo / 2, vv);
         else store4(Og + ((long)b * p.S + q) * p.ldo + head * D + d, vv);
     };
     if (nactive == 0) {   // nothing contributes to this output row: zeros (workgroup-uniform: no barrier has been executed yet)

@@ -260,12 +260,15 @@ static bool is_pp_cfg(int cfg) { return cfg >= CFG_PP_256x320 && cfg <= CFG_PP_1
 // whether the ping-pong kernel (igemm_p8.h) handles this problem on a bm x bn tile: its restrictions are listed in that header
 static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn, int splitk = 1) {
     const long lim = (1l << 31) - 4096;
-    if (d.K % 64 != 0 || d.K < 128 || d.N % bn != 0 || d.M < bm) return false;
+    // K tiles of the kernel: 64 bf16 elements; split-bf16 (d.K = the virtual 3 K): one 128-byte block [hi(32) | lo(32)] = 32 real elements
+    const int nkt = d.x3 ? d.K / 96 : d.K / 64;
+    if (d.x3) {
+        if (d.x3 != 2 || d.K % 96 != 0 || d.a_lo != 32) return false;             // blocked operands only
+    } else if (d.K % 64 != 0) return false;
+    if (nkt < 2 || d.N % bn != 0 || d.M < bm) return false;
     const int osz = d.x3 ? 4 : 2;                                  // bytes per output / residual element
-    if (d.x3 && (d.x3 != 2 || (d.K / 3) % 64 != 0 || d.a_lo % 8 != 0)) return false;      // chunk-ordered W, whole 64-element chunks
-    if (d.x3 && splitk > 1 && (d.K / 192) % splitk != 0) return false;                    // K slices of whole chunks (three K tiles each)
-    if (splitk > 1) {       // split-K: raw fp32 slabs + igemm_splitk_reduce_kernel (which applies every plain epilogue option)
-        if (!can_split(d) || (d.K / 64) % splitk != 0 || d.K / 64 / splitk < 2 || (long)splitk * d.M * d.N * 4 > d.ws_bytes || (long)splitk * d.M * d.N * 4 >= lim) return false;
+    if (splitk > 1) {       // split-K: raw fp32 slabs + igemm_splitk_reduce_kernel (which applies every plain epilogue option); slices of whole K tiles
+        if (!can_split(d) || nkt % splitk != 0 || nkt / splitk < 2 || (long)splitk * d.M * d.N * 4 > d.ws_bytes || (long)splitk * d.M * d.N * 4 >= lim) return false;
     } else {
         // GELU / RELU: applied by the plain bf16 epilogue, whose accumulators start at the bias -- not beside a residual (it starts there too)
         const int act_ok = (!d.residual && !d.x3 && !d.f8 && !(d.flags & FFN_IG_GEGLU)) ? (FFN_IG_OUT_GELU | FFN_IG_OUT_RELU) : 0;
@@ -278,9 +281,11 @@ static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn, int splitk = 1) {
     long a_bytes;
     if (d.conv) {
         const int pix = d.x3 ? d.lda : d.Cin;                      // elements per input pixel
-        if (d.Cin % 64 != 0 || d.K != (d.conv == 2 ? 4 : 9) * (d.x3 ? 3 : 1) * d.Cin) return false;
+        const int cpt = d.x3 ? d.Cin / 32 : d.Cin / 64;            // K tiles per tap
+        if (d.Cin % (d.x3 ? 32 : 64) != 0 || d.K != (d.conv == 2 ? 4 : 9) * (d.x3 ? 3 : 1) * d.Cin) return false;
+        if (d.x3 && d.lda != 2 * d.Cin) return false;
         if (d.conv == 2 && (d.f8 || d.stride != 1 || d.upsample)) return false;
-        if (d.x3 ? (d.Cin / 64 >= 100) : (d.Cin / 64 * 9 * (d.Cin / 64) >= 65536)) return false;      // exactness range of the tap reciprocal
+        if ((long)cpt * 9 * cpt >= 65536) return false;            // exactness range of the tap reciprocal
         a_bytes = (long)(d.M / (d.Hout * d.Wout)) * d.Hin * d.Win * pix * 2;
         if (2 * d.Hin + 2 >= 32768 || 2 * d.Win + 2 >= 32768) return false;
         if (a_bytes + 256l * pix * 2 >= lim) return false;
@@ -533,7 +538,7 @@ static int candidates_for(const ffn_igemm_desc& d, IgChoice* out, int cap) {
             const long pt = (long)((d.M + c.bm - 1) / c.bm) * (d.N / (c.bn > 0 ? c.bn : 1));
             if (d.splitk <= 1 && pp_ok(d, c.bm, c.bn) && n < cap) out[n++] = IgChoice{cfg, 1};
             if (d.splitk != 1 && pt > 0 && pt < 160 && d.N % c.bn == 0) {
-                const int nkt = d.K / 64;
+                const int nkt = d.x3 ? d.K / 96 : d.K / 64;
                 int added = 0;
                 for (int sgo = (int)((384 + pt - 1) / pt); sgo >= 2 && added < 2; --sgo) {
                     if (d.splitk > 1 && sgo != d.splitk) continue;
@@ -649,7 +654,7 @@ static int tuned_bf16(hipStream_t s, const ffn_igemm_desc& d) {
 // entry = [stamp | TuneKey | cfg | splitk]; the stamp names the layout of this build's table (key size, configuration list, arch):
 // entries written by a different build are ignored on import
 static constexpr int kTuneEntryInts = (int)(sizeof(TuneKey) / sizeof(int)) + 3;
-static constexpr int kTuneStamp = 0x67780000 ^ (950 << 4) ^ ((int)sizeof(TuneKey) << 8) ^ CFG_COUNT ^ (3 << 24);      // gfx950, table layout 3
+static constexpr int kTuneStamp = 0x67780000 ^ (950 << 4) ^ ((int)sizeof(TuneKey) << 8) ^ CFG_COUNT ^ (4 << 24);      // gfx950, table layout 4 (round 5: blocked split-bf16 operands)
 extern "C" int ffn_igemm_tune_entry_ints(void) { return kTuneEntryInts; }
 extern "C" int ffn_igemm_tune_stamp(void) { return kTuneStamp; }
 extern "C" int ffn_igemm_tune_clear(void) {
@@ -811,7 +816,7 @@ static int dispatch_igemm(hipStream_t s, const ffn_igemm_desc& d) {
 // the library's private view of a split-bf16 problem: the kernels and the tile / split-K logic see the VIRTUAL contraction 3K
 static ffn_igemm_desc x3_view(const ffn_igemm_desc& d) {
     ffn_igemm_desc v = d;
-    v.x3 = d.x3 == 2 ? 2 : 1;          // order of W's virtual contraction: 1 = plane, 2 = chunk (64-element chunks)
+    v.x3 = d.x3 == 2 ? 2 : 1;          // operand layout: 1 = planes, 2 = 128-byte blocks [hi(32) | lo(32)] (include/freefine_hip.h)
     v.f8 = 0;
     v.K = 3 * d.K;
     v.flags |= FFN_IG_OUT_F32;
@@ -871,16 +876,19 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
         return tuned_bf16<AMODE_CONV3, false, true>(reinterpret_cast<hipStream_t>(stream), f8_view(*d));
     }
     const int epc = dtype == FFN_F32 ? 4 : 8, kstage = 8 * epc;
-    const int kmul = dtype == FFN_BF16X3 ? 3 : 1;
+    const int kmul = dtype == FFN_BF16X3 ? (d->x3 == 2 ? 2 : 3) : 1;       // W row: [hi | lo | hi] planes (3 K) or [hi(32) | lo(32)] blocks (2 K)
     REQUIRE(d->A && d->W && d->out, "igemm: null A/W/out");
     REQUIRE(aligned16(d->A) && aligned16(d->W) && aligned16(d->out), "igemm: A/W/out must be 16-byte aligned");
     REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "igemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
-    REQUIRE(d->Kpad >= kmul * d->K && d->Kpad % epc == 0, "igemm: Kpad=%d (row stride of W) must be >= K=%d and a multiple of %d", d->Kpad, kmul * d->K, epc);
+    REQUIRE(d->Kpad >= kmul * d->K && d->Kpad % epc == 0, "igemm: Kpad=%d (row stride of W) must be >= %d x K=%d and a multiple of %d", d->Kpad, kmul, d->K, epc);
     if (dtype == FFN_BF16X3) {
         const int plane = d->conv ? d->Cin : d->K;
-        REQUIRE(d->a_lo % 8 == 0 && d->a_lo >= plane && d->a_lo + plane <= d->lda, "igemm: split-bf16 A needs planes of %d elements: a_lo=%d, lda=%d", plane, d->a_lo, d->lda);
+        if (d->x3 == 2) {
+            REQUIRE(plane % 32 == 0 && d->a_lo == 32 && d->lda >= 2 * plane, "igemm: blocked split-bf16 operands need K (conv: Cin) %% 32 == 0, a_lo = 32, lda >= 2 x that (%d, a_lo=%d, lda=%d)", plane, d->a_lo, d->lda);
+        } else {
+            REQUIRE(d->a_lo % 8 == 0 && d->a_lo >= plane && d->a_lo + plane <= d->lda, "igemm: split-bf16 A needs planes of %d elements: a_lo=%d, lda=%d", plane, d->a_lo, d->lda);
+        }
         REQUIRE(d->lda % 8 == 0, "igemm: lda=%d must be a multiple of 8", d->lda);
-        if (d->x3 == 2) REQUIRE(plane % 64 == 0, "igemm: chunk-ordered split-bf16 weights need K (conv: Cin) %% 64 == 0 (%d)", plane);
         REQUIRE(d->alpha == 1.0f, "igemm: split-bf16 problems take alpha = 1");
         if (d->residual) REQUIRE(aligned16(d->residual), "igemm: fp32 residual must be 16-byte aligned");
     }
@@ -896,7 +904,7 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
             bool any = false;
             for (int bn : {320, 256})
                 for (int h : {256, 192}) any |= d->N % bn == 0 && pp_ok(v, h, bn);
-            REQUIRE(any, "igemm: 2x2 convolution M=%d N=%d Cin=%d fits no ping-pong tile (Cin %% 64, N %% 256 / 320, M >= 192)", d->M, d->N, d->Cin);
+            REQUIRE(any, "igemm: 2x2 convolution M=%d N=%d Cin=%d fits no ping-pong tile (Cin %% 64 (split-bf16: 32), N %% 256 / 320, M >= 192)", d->M, d->N, d->Cin);
         } else {
             REQUIRE(d->conv == 1, "igemm: conv=%d", d->conv);
             REQUIRE(d->K == 9 * d->Cin, "igemm: conv K=%d != 9*Cin=%d", d->K, 9 * d->Cin);
@@ -917,6 +925,7 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
         if (d->flags & FFN_IG_OUT_PAIR) {
             const int nout = (d->flags & FFN_IG_GEGLU) ? d->N / 2 : d->N;
             REQUIRE(dtype == FFN_BF16X3 && !d->residual && d->ldo % 16 == 0 && d->ldo / 2 >= nout, "igemm: pair output needs FFN_BF16X3, no residual, ldo %% 16 == 0, ldo/2 >= columns");
+            REQUIRE((d->ldo / 2) % 32 != 0 || nout % 32 == 0 || nout == d->ldo / 2, "igemm: blocked pair output (ldo/2 %% 32 == 0) needs whole 32-column blocks");
         }
         if (d->flags & FFN_IG_GEGLU) {
             REQUIRE(d->N % 64 == 0, "igemm: GEGLU needs N %% 64 == 0 (N=%d)", d->N);

@@ -197,6 +197,12 @@ __device__ __forceinline__ float gelu_for(float x) {
     else return gelu_erf(x);
 }
 
+// The split-bf16 PAIR form of a row of C fp32 values (FFN_BF16X3 A operands; include/freefine_hip.h): bf16 [2C].  C % 32 == 0 -> BLOCKED: every 32
+// columns are one 128-byte block [hi(32) | lo(32)], so that a 32-deep K stage of the GEMM is one whole 128-byte line holding both planes
+// (column c: hi at 64 (c / 32) + c % 32, lo 32 elements behind it); otherwise one block of C columns = the planes [hi(C) | lo(C)].
+__device__ __forceinline__ int pair_pos(int c, int C) { return (C & 31) ? c : ((c >> 5) << 6) + (c & 31); }
+__device__ __forceinline__ int pair_lo(int C) { return (C & 31) ? C : 32; }
+
 // Bijective XCD-aware remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch), so give
 // every XCD a contiguous run of logical tiles (neighbouring tiles share operand panels -> L2 hits).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

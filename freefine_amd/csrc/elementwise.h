@@ -134,8 +134,9 @@ __global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ src, T
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) DT<TD>::st(dst + i, DT<TS>::ld(src + i));
 }
 
-// fp32 [rows][ld_src] (first C columns) -> the split-bf16 PAIR form the FFN_BF16X3 GEMMs read: bf16 [rows][2C], hi = bf16(x) (RNE) in
-// columns [0, C), lo = bf16(x - hi) in [C, 2C).  hi + lo carries 16-17 significant bits of x; 4 elements (16 B in, 2 x 8 B out) per thread.
+// fp32 [rows][ld_src] (first C columns) -> the split-bf16 PAIR form the FFN_BF16X3 GEMMs read: bf16 [rows][2C], hi = bf16(x) (RNE),
+// lo = bf16(x - hi), laid out by common.h pair_pos (C % 32 == 0: 128-byte blocks [hi(32) | lo(32)]; else the planes [hi(C) | lo(C)]).
+// hi + lo carries 16-17 significant bits of x; 4 elements (16 B in, 2 x 8 B out) per thread.
 __global__ __launch_bounds__(256) void split_pair_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long rows, int C, int ld_src) {
     const int cq = C >> 2;
     const long n = rows * cq;
@@ -148,8 +149,9 @@ __global__ __launch_bounds__(256) void split_pair_kernel(const float* __restrict
         hi[1] = pack_bf16x2(x[2], x[3]);
         lo[0] = pack_bf16x2(x[0] - __uint_as_float(hi[0] << 16), x[1] - __uint_as_float(hi[0] & 0xffff0000u));
         lo[1] = pack_bf16x2(x[2] - __uint_as_float(hi[1] << 16), x[3] - __uint_as_float(hi[1] & 0xffff0000u));
-        *reinterpret_cast<u32x2*>(dst + r * 2 * C + c) = hi;
-        *reinterpret_cast<u32x2*>(dst + r * 2 * C + C + c) = lo;
+        bf16* q = dst + r * 2 * C + pair_pos(c, C);
+        *reinterpret_cast<u32x2*>(q) = hi;
+        *reinterpret_cast<u32x2*>(q + pair_lo(C)) = lo;
     }
 }
 

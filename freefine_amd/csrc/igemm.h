@@ -31,8 +31,10 @@ __device__ __forceinline__ float ig_activation(float x, int flags) {
     if (flags & IG_OUT_RELU) return fmaxf(x, 0.f);
     return x;
 }
-// four fp32 values -> the bf16 pair form (hi at p, lo at p + lo_off), 8 bytes each
-__device__ __forceinline__ void store_pair_row4(bf16* p, int lo_off, const float* v) {
+// four fp32 values, columns c .. c + 3 (c % 4 == 0) of a row of C -> the bf16 pair form of that row (common.h pair_pos), 8 bytes each
+__device__ __forceinline__ void store_pair_row4(bf16* row, int c, int C, const float* v) {
+    bf16* p = row + pair_pos(c, C);
+    const int lo_off = pair_lo(C);
     u32x2 hi, lo;
     hi[0] = pack_bf16x2(v[0], v[1]);
     hi[1] = pack_bf16x2(v[2], v[3]);
@@ -92,7 +94,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
                             v[r] = h * gelu_for<T>(gt);
                         }
                         const int no = (nbase) / 2 + (j / 2) * 16 + 4 * g;
-                        if (p.flags & IG_OUT_PAIR) store_pair_row4(reinterpret_cast<bf16*>(p.out) + (long)m * p.ldo + no, p.ldo / 2, v);
+                        if (p.flags & IG_OUT_PAIR) store_pair_row4(reinterpret_cast<bf16*>(p.out) + (long)m * p.ldo, no, p.ldo / 2, v);
                         else store4(outT + (long)m * p.ldo + no, v);
                     }
                 }
@@ -122,7 +124,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
                             for (int r = 0; r < 4; ++r) v[r] += rr[r];
                         }
                         if (p.flags & IG_OUT_PAIR)
-                            store_pair_row4(reinterpret_cast<bf16*>(p.out) + (long)m * p.ldo + n, p.ldo / 2, v);
+                            store_pair_row4(reinterpret_cast<bf16*>(p.out) + (long)m * p.ldo, n, p.ldo / 2, v);
                         else if (out_f32)
                             store4(outF + (long)m * p.ldo + n, v);
                         else
@@ -340,9 +342,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // FASTK: the caller guarantees K % 64-byte-stage == 0 (dense) / Cin % stage == 0 (conv): the streaming loader below is used
 // X3 (FFN_BF16X3, "split-bf16"): every fp32 value is carried as hi + lo (two bf16) and a product as hi*hi + hi*lo + lo*hi on the bf16
 // MFMA with fp32 accumulation.  Nothing changes in the multiplier: the GEMM simply runs over a VIRTUAL contraction of 3K --
-//   A: pair-format rows [hi(0..K) ... | lo at column a_lo ...] read as segments [A_hi | A_hi | A_lo]   (p.K holds 3K, Kr = K)
-//   W: packed [N][3K] = [W_hi | W_lo | W_hi] (conv: per tap), plain rows -- "plane order" (p.x3 == 1), or, where K (conv: Cin) is a
-//      multiple of 64, "chunk order" (p.x3 == 2): that triple per 64-element chunk, which lets the ping-pong kernel stage each half tile once
+//   "plane order" (p.x3 == 1; any K % 8 == 0):  A pair rows [hi(K) | lo(K)] read as segments [A_hi | A_hi | A_lo], W packed [N][3K] =
+//      [W_hi | W_lo | W_hi] (conv: per tap)                                                            (p.K holds 3K, Kr = K)
+//   "blocked" (p.x3 == 2; K, conv: Cin, % 32 == 0):  A and W both as 128-byte blocks [hi(32) | lo(32)] per 32 elements (W: [N][2K]); the three
+//      segments are taken per block (see the loader).  This is the layout the ping-pong kernel's split-bf16 core (igemm_p8.h) streams.
 // so only the loader's K -> (tap, column) map differs.  Output / residual are fp32 (epilogue instantiated for float).
 // F8 (FFN_FP8): A and W hold OCP e4m3 bytes; the library hands the kernels a bf16-SHAPED view of the problem (K, Cin, lda, Kpad in units of
 // two bytes), so nothing in the addressing changes -- only the multiply (mma_fp8: two fp8 MFMAs per 16-byte chunk pair) and the scale
@@ -427,11 +430,17 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
     auto issue = [&](int kt, int buf) {
         const int kk = kt * BKE + csrc * EPC;
         const bool kin = kk < p.K;
+        // X3 with blocked operands (p.x3 == 2): the virtual contraction visits, per 32-element block b of the real K, the three segments
+        //   seg 0: A_hi[b] x W_hi[b]     seg 1: A_hi[b] x W_lo[b]     seg 2: A_lo[b] x W_hi[b]
+        // (96 virtual elements per block); A and W both store the block as [hi(32) | lo(32)] (64 elements), so kk -> (b, seg, e) gives
+        // A offset 64 b + e + (seg == 2 ? 32 : 0) and W offset 64 b + e + (seg == 1 ? 32 : 0).  A 16-byte chunk (8 elements) never straddles.
+        int kb = kk;                                   // W column of this lane's chunk
         if (AMODE == AMODE_DENSE) {
             int ka = kk;
-            if (X3 && p.x3 == 2) {                // chunk order: [hi(64) | lo(64) | hi(64)] of W per 64-element chunk of K; A: hi, hi, lo
-                const int blk = kk / 192, w = kk - blk * 192, seg = w >> 6;
-                ka = blk * 64 + (w & 63) + (seg == 2 ? p.a_lo : 0);
+            if (X3 && p.x3 == 2) {
+                const int blk = kk / 96, w = kk - blk * 96, seg = w >> 5, e = w & 31;
+                ka = blk * 64 + e + (seg == 2 ? 32 : 0);
+                kb = blk * 64 + e + (seg == 1 ? 32 : 0);
             } else if (X3) {                      // plane order: segment 0, 1: hi plane; segment 2: lo plane (a chunk never straddles: Kr % 8 == 0)
                 const int seg = (kk >= Kr) + (kk >= 2 * Kr);
                 ka = kk - seg * Kr + (seg == 2 ? p.a_lo : 0);
@@ -447,8 +456,9 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
             if (X3 && p.x3 == 2) {
                 const int c3 = 3 * p.Cin;
                 tap = kk / c3;
-                const int r = kk - tap * c3, blk = r / 192, w = r - blk * 192, seg = w >> 6;
-                ci = blk * 64 + (w & 63) + (seg == 2 ? p.a_lo : 0);
+                const int r = kk - tap * c3, blk = r / 96, w = r - blk * 96, seg = w >> 5, e = w & 31;
+                ci = blk * 64 + e + (seg == 2 ? 32 : 0);
+                kb = tap * 2 * p.Cin + blk * 64 + e + (seg == 1 ? 32 : 0);
             } else if (X3) {
                 const int c3 = 3 * p.Cin;
                 tap = kk / c3;
@@ -474,7 +484,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void igemm_glds_kernel(const IgemmP
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             if (GB % NW != 0 && wave + NW * i >= GB) continue;
-            const char* src = (b_ok[i] && kin) ? reinterpret_cast<const char*>(Wg + b_base[i] + kk) : zero;
+            const char* src = (b_ok[i] && kin) ? reinterpret_cast<const char*>(Wg + b_base[i] + kb) : zero;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + buf * BN * 128 + (8 * (wave + NW * i)) * 128), 16, 0, 0);
         }
     };
@@ -815,7 +825,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmPar
             for (int r = 0; r < 4; ++r) v[r] += rr[r];
         }
         if (p.flags & IG_OUT_PAIR)
-            store_pair_row4(reinterpret_cast<bf16*>(p.out) + (long)m * p.ldo + n, p.ldo / 2, v);
+            store_pair_row4(reinterpret_cast<bf16*>(p.out) + (long)m * p.ldo, n, p.ldo / 2, v);
         else if (p.flags & IG_OUT_F32)
             store4(outF + (long)m * p.ldo + n, v);
         else

@@ -71,20 +71,22 @@ __device__ __forceinline__ void pp_barrier() {
 #ifdef PP_TRACE
 __device__ unsigned long long pp_trace[256 * 64];   // tools/native/pp_bench.hip: 100 MHz timestamps around the low-row stores of each tile
 #endif
-// X3 (FFN_BF16X3, split-bf16 operands; see igemm.h): the multiplier is untouched -- the K-tile stream runs over the virtual contraction
-// of 3 K in CHUNK order (p.x3 == 2): every 64-element chunk c of the real contraction contributes three consecutive K tiles
-//     T0 = A_hi[c] x W_hi[c]      T1 = A_hi[c] x W_lo[c]      T2 = A_lo[c] x W_hi[c]
-// (W is packed in exactly that order, so its K position stays linear; A's is a scalar function of the K-tile counter).  Consecutive tiles
-// share an operand, so each of the four half tiles is STAGED ONCE per chunk instead of six stagings: the two A slots and the two B slots of
-// the LDS double buffer are assigned separately --
-//     A_hi[c] -> A slot 0 (read by T0, T1; re-staged during T2)          A_lo[c] -> A slot 1 (read by T2; re-staged during the next T1)
-//     W_hi[c] -> B slot c & 1 (read by T0, T2)                            W_lo[c] -> the other B slot (read by T1)
-// which keeps every re-staging >= 2 phases behind the slot's last read (the WAR rule above) -- and a tile only requests what the NEXT tile
-// does not already have: T2 requests A_hi and W_hi of the next chunk (the full set), T0 only W_lo (B pieces: phases 1-2, then nothing; its
-// phase-4 wait is vmcnt(0)), T1 only A_lo (A pieces: phases 3-4; its phase-1 wait is vmcnt(0)).  18 instead of 27 LDS-DMA pieces per chunk
-// and wave in a kernel whose bound is the issue of those pieces.  K slices of a split-K launch are whole chunks.
-// Output and residual are fp32: accumulators start at bias + row bias + fp32 residual, the epilogue stores 16 bytes per lane through the
-// same lane permutation as the split-K slabs.
+// X3 (FFN_BF16X3, split-bf16 operands; round 5: "core v2").  Operands arrive in the BLOCKED pair form (include/freefine_hip.h): every 32 elements of
+// the contraction are one 128-byte block [hi(32) | lo(32)] -- of an A row / pixel and of a W row alike -- so to the LOADER this is simply a bf16
+// GEMM over 2 K elements: a K tile ("stage") is 32 real elements deep, its LDS row holds the hi fragment chunks (16-byte chunks 0-3) and the lo ones
+// (chunks 4-7) of the same 32 elements, every 128-byte line is fetched whole and ONCE, and nothing of the K position logic is special.
+// The MULTIPLIER differs: a stage is consumed in TWO phases (low rows, high rows) instead of four, and each phase issues the three products
+//     A_hi x W_hi,   A_lo x W_hi,   A_hi x W_lo
+// of its FH x FN fragment pairs back to back from ONE set of fragment reads (a_hi, a_lo of the phase's rows; w_hi, w_lo read in phase L and kept
+// in registers for phase H; the 256 x 320 tile, 160 accumulator registers, holds one A set and fetches a_lo over a_hi behind the second product).  Against round 3/4's form (the bf16 kernel run over a virtual contraction of 3 K in
+// chunk order: three K tiles = 12 phases = 24 barriers and six fragment sets per 64 elements) that is 4 phases = 8 barriers and four fragment sets
+// per 64 elements, with 45-60 MFMAs (720-960 cycles) per phase beside the partner wave's load section instead of 16-20.
+// LDS-DMA schedule per stage and wave: phase L requests the next stage's W pieces and its low A pieces, phase H its high A pieces; waits: end of
+// phase H (W + A-low of the next stage landed, the high A pieces just requested may fly), end of phase L (A-high landed) -- every piece has a full
+// phase to land.  WAR: the other buffer's W and low A rows were last read in phase L of the previous stage (two phases back), its high A rows in
+// phase H of the previous stage (two phases back from this stage's phase H).
+// K slices of a split-K launch are whole stages.  Output and residual are fp32: accumulators start at bias + row bias + fp32 residual, the epilogue
+// stores 16 bytes per lane through the same lane permutation as the split-K slabs; GEGLU writes the blocked pair form for the next GEMM.
 // F8 (FFN_FP8, 3x3 convolutions): fp8 e4m3 operands in the bf16 byte geometry (the library passes a bf16-shaped view: K, Cin, Kpad in
 // two-byte units), so a K tile carries 128 real elements and each fragment pair takes TWO fp8 MFMAs -- twice the MFMA work per LDS-DMA
 // piece of a kernel whose bound is the issue of those pieces.  Operands are pre-scaled by powers of two (activations 2^4, weights per
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     const int nsl = SPLIT ? splitk : 1;               // K slices per output tile (the launcher picks a divisor of K / 64)
     const int ntiles = ntm * ntn * nsl;               // walk index = output tile * nsl + slice
     const int G = gridDim.x;
-    const int nk = p.K / 64 / nsl;                    // K tiles per walk step
+    const int nk = (X3 ? p.K / 96 : p.K / 64) / nsl;  // K tiles per walk step (X3: p.K is the virtual 3 K, a K tile = 32 real elements = one 128-byte [hi | lo] block)
     const int first = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, G));
     const int my_tiles = (ntiles - first + G - 1) / G;
     const int S = my_tiles * nk;                      // K tiles this workgroup multiplies, in stream order
@@ -174,33 +176,20 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     // (the nine taps of a chunk back to back) and (ky, chunk, kx) -- and both run 5-13 % SLOWER (310 / 313 vs 289 us at M = 196608,
     // Cin = 320; 373 vs 339 us at 32x32 x 640): the launch is not bound by where its lines come from, and the strided walks lose more
     // (requests to lines still in flight, weight rows no longer streamed) than the L2 hits return.
-    // X3: a tap is 3 cptr K tiles (three per 64-element chunk, see the header); a dense problem is one "tap" of cptr = K / 64 chunks.
-    // The 20-bit reciprocal is exact while kt * cpt < 2^20 (kt < 9 cpt, cpt < 341).
-    const int cptr = AMODE == AMODE_DENSE ? (X3 ? p.K / 192 : 1) : p.Cin / 64;      // real 64-element chunks per tap
-    const int cpt = X3 ? 3 * cptr : cptr;
-    const int cpt_rcp = X3 ? ((1 << 20) + cpt - 1) / cpt : (65536 + cpt - 1) / cpt;
-    const int lo_bytes = X3 ? p.a_lo * 2 : 0;
+    // X3: a pixel's Cin channels are Cin / 32 blocks [hi(32) | lo(32)] of 128 bytes = Cin / 32 K tiles per tap (PIX = 4 Cin bytes per pixel)
+    const int cpt = AMODE == AMODE_DENSE ? 1 : (X3 ? p.Cin / 32 : p.Cin / 64);      // K tiles per tap
+    const int cpt_rcp = (65536 + cpt - 1) / cpt;
     int ka = 0, tap_ky = 0, tap_kx = 0, tap_off = 0;  // of K tile l_kt; set by k_position()
     auto k_position = [&]() {
         const int kt = l_k0 + l_kt;
-        if constexpr (X3) {                           // chunk order: tile r of a tap = (chunk r / 3, segment r % 3); segments 0, 1 read the hi plane, 2 the lo plane
-            const int tap = AMODE == AMODE_DENSE ? 0 : (kt * cpt_rcp) >> 20;
-            const int r = kt - tap * cpt;
-            const int c = (r * 21846) >> 16;
-            ka = c * 128 + (r - 3 * c == 2 ? lo_bytes : 0);
-            if (AMODE != AMODE_DENSE) {
-                tap_ky = p.conv == 2 ? (tap >> 1) : ((tap * 21846) >> 16);
-                tap_kx = tap - (p.conv == 2 ? 2 : 3) * tap_ky;
-                tap_off = (tap_ky * p.Win + tap_kx) * PIX;
-            }
-        } else if (AMODE == AMODE_DENSE) {
+        if (AMODE == AMODE_DENSE) {
             ka = kt * 128;
         } else {
             const int tap = (kt * cpt_rcp) >> 16;
             ka = (kt - tap * cpt) * 128;
             tap_ky = p.conv == 2 ? (tap >> 1) : ((tap * 21846) >> 16);       // taps per window row: 2 (conv == 2) or 3
             tap_kx = tap - (p.conv == 2 ? 2 : 3) * tap_ky;
-            tap_off = (tap_ky * p.Win + tap_kx) * p.Cin * 2;
+            tap_off = (tap_ky * p.Win + tap_kx) * PIX;
         }
     };
     auto prep = [&](int wtile) {                      // loader state at the first K tile of walk step `wtile`
@@ -355,12 +344,16 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcR, voff, ((m0 + i * 16) * p.ldr + n0 + j * 16) * 4, 0));
+            // column by column: (bias + row bias of the first image) and (bias + row bias of the next image) of the lane's four columns, selected per
+            // fragment row -- 8 live registers instead of two LDS reads per fragment (round 5: the split-bf16 core holds up to 72 fragment registers)
 #pragma unroll
-            for (int i = i0; i < i0 + FH; ++i) {
-                const int rb_off = (i * 16 + l15 >= E) ? 1024 : 512;
+            for (int j = 0; j < FN; ++j) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(slot + (j * 16 + 4 * g) * 4);
+                const f32x4 c0 = bv + *reinterpret_cast<const f32x4*>(slot + 512 + (j * 16 + 4 * g) * 4);
+                const f32x4 c1 = bv + *reinterpret_cast<const f32x4*>(slot + 1024 + (j * 16 + 4 * g) * 4);
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] += *reinterpret_cast<const f32x4*>(slot + (j * 16 + 4 * g) * 4) + *reinterpret_cast<const f32x4*>(slot + rb_off + (j * 16 + 4 * g) * 4);
+                for (int i = i0; i < i0 + FH; ++i) acc[i][j] += (i * 16 + l15 >= E) ? c1 : c0;
+                __builtin_amdgcn_sched_barrier(0);
             }
             return;
         }
@@ -473,7 +466,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
 #pragma unroll
             for (int i = i0; i < i0 + FH; ++i) {
                 const int vo = m0 + i * 16 + pr < p.M ? voff : OOB;
-                if constexpr (GEGLU) {                // pair form: out is bf16 [M][ldo], hi at column n, lo at ldo/2 + n
+                if constexpr (GEGLU) {                // blocked pair form: out is bf16 [M][ldo]; the wave's 32 output columns n0/2 .. n0/2 + 31 are ONE
+                                                      // 128-byte block [hi(32) | lo(32)] at element (n0/2 / 32) * 64 (ldo / 2 = output columns, % 32 == 0)
                     const int vo2 = m0 + i * 16 + pr < p.M ? (pr * p.ldo + 4 * pg) * 2 : OOB;
 #pragma unroll
                     for (int j = 0; j + 1 < FN; j += 2) {
@@ -486,9 +480,9 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
                         lo[0] = pack_bf16x2(v[0] - __uint_as_float(hi[0] << 16), v[1] - __uint_as_float(hi[0] & 0xffff0000u));
                         lo[1] = pack_bf16x2(v[2] - __uint_as_float(hi[1] << 16), v[3] - __uint_as_float(hi[1] & 0xffff0000u));
                         hi[0] = perm(hi[0]); hi[1] = perm(hi[1]); lo[0] = perm(lo[0]); lo[1] = perm(lo[1]);
-                        const int so = ((m0 + i * 16) * p.ldo + n0 / 2 + (j / 2) * 16) * 2;
+                        const int so = ((m0 + i * 16) * p.ldo + n0 + (j / 2) * 16) * 2;      // block base = 2 * (n0 / 2) elements (n0 / 2 % 32 == 0)
                         __builtin_amdgcn_raw_buffer_store_b64(hi, rsrcO, vo2, so, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(lo, rsrcO, vo2, so + p.ldo, 0);      // + ldo/2 elements = ldo bytes
+                        __builtin_amdgcn_raw_buffer_store_b64(lo, rsrcO, vo2, so + 64, 0);         // lo: 32 elements behind hi
                     }
                 } else {
 #pragma unroll
@@ -605,126 +599,231 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
 
     int c_tile = first, c_kt = 0, buf = 0;
     int p_tile = -1;                                  // tile whose high rows still sit in the accumulators (-1: none)
-    int ty = 0, cp = 0;                               // X3: segment of this K tile (0, 1, 2) and parity of its chunk along the stream
-    for (int s = 0; s < S; ++s) {
-        const bool more = s + 1 < S;                  // another K tile follows in this workgroup's stream: request it during this one
-        const int nb = buf ^ 1;
-        // LDS slots this tile READS its A / B fragments from (ra, rb), slots the next tile's operands are STAGED into (la, lb), and which
-        // of the two the next tile still needs (plain kernels: both, the other buffer)
-        int ra = buf, rb = buf, la = nb, lb = nb;
-        bool needA = more, needB = more;
-        if constexpr (X3) {
-            const int nty = ty == 2 ? 0 : ty + 1, ncp = ty == 2 ? cp ^ 1 : cp;
-            ra = ty == 2 ? 1 : 0;
-            rb = ty == 1 ? cp ^ 1 : cp;
-            la = nty == 2 ? 1 : 0;
-            lb = nty == 1 ? ncp ^ 1 : ncp;
-            needA = more && nty != 1;
-            needB = more && nty != 2;
-        }
-
-        // ---- phase 1: low rows, k-substep 0 ----
-        __builtin_amdgcn_sched_barrier(0);
-        if (p_tile < 0) {
-            read_a(ra, a_rd0, 0);
-            read_b(rb, b_rd0);
-        }
-        if (p_tile >= 0) {
-            // first K tile of a new output tile (never the last K tile of the stream: nk >= 2).  The previous tile's high rows, final
-            // since the phase-4 MFMAs, leave now; its low rows left in that phase 4.  The VM counter is in order and counts stores:
-            // a wait that only needs loads OLDER than the stores names the stores (and the residual loads behind them) as allowed
-            // in flight, so no wait of the K loop ever sits behind a store's round trip.  Queue, oldest first:
-            //   A-high of this K tile | next tile's column vectors | low stores | high stores | B x NB1
-            // (the residual loads of init_rows are the compiler's: it drains the counter at their first use)
-            store_rows(p_tile, I4_t{});                // (X3: the first K tile of an output tile is a T0: the next tile needs its B pieces)
+    if constexpr (X3) {
+        // ---- split-bf16 core v2: two phases per stage (32 real K elements), three products per fragment pair from one set of fragment reads ----
+        // KEEPA: a_hi and a_lo of a phase's rows both sit in registers.  The 256 x 320 tile (160 accumulator registers) holds ONE A set and
+        // fetches a_lo over a_hi's registers behind the second product (A rows are re-staged two phases after their phase: safe for a read inside
+        // the MFMA section; W rows are re-staged in the very next phase L, so W fragments are only ever read in phase L's load section).
+        constexpr bool KEEPA = !(BM == 256 && BN == 320);
+        constexpr int NAL = 2, NAH = NA - 2;                   // A pieces requested in phase L (every low piece is among them) / in phase H
+        u32x4 fal[KEEPA ? FH : 1], fbl[FN];                    // lo fragments (fa / fb hold the hi ones); w_hi / w_lo stay for both phases of a stage
+        auto mfma3 = [&](auto I0, int b_) {
+            constexpr int i0 = decltype(I0)::value;
+            if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < NB1; ++i) issue_b(i, lb);
-            pp_wait_vmcnt<NB1 + 2 * NST>();           // through A-high
-            init_rows(c_tile, I0_t{});
-            __builtin_amdgcn_sched_barrier(0);        // the fragment reads last: their registers are free for the epilogue's temporaries
-            read_a(ra, a_rd0, 0);
-            read_b(rb, b_rd0);
-        } else if (needB) {
+            for (int i = 0; i < FH; ++i)
 #pragma unroll
-            for (int i = 0; i < NB1; ++i) issue_b(i, lb);
-            pp_wait_vmcnt<NB1>();                     // A-high of THIS K tile (requested in phase 4 of the previous one) has landed
-        } else {
-            pp_wait_vmcnt<0>();                       // last K tile of the stream, or an X3 T1 (nothing requested for it after the previous tile's wait)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        pp_barrier();
-        mfma_rows(I0_t{});
-        __builtin_amdgcn_sched_barrier(0);
-        pp_barrier();
-
-        // ---- phase 2: high rows, k-substep 0 ----
-        read_a(ra, a_rd0, FH);
-        if (needB) {
+                for (int j = 0; j < FN; ++j) DT<T>::mma(fb[j], fa[i], acc[i0 + i][j]);                  // A_hi x W_hi
+            if constexpr (KEEPA) {
 #pragma unroll
-            for (int i = NB1; i < FN; ++i) issue_b(i, lb);
-        }
-        if (p_tile >= 0) {                            // the high rows of the new tile start
-            init_rows(c_tile, I4_t{});
-            p_tile = -1;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        pp_barrier();
-        mfma_rows(I4_t{});
-        __builtin_amdgcn_sched_barrier(0);
-        pp_barrier();
-
-        // ---- phase 3: low rows, k-substep 1 ----
-        read_a(ra, a_rd1, 0);
-        read_b(rb, b_rd1);
-        if (needA) {
-            k_position();
-            issue_a(0, la);
-            issue_a(1, la);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        pp_barrier();
-        mfma_rows(I0_t{});
-        __builtin_amdgcn_sched_barrier(0);
-        pp_barrier();
-
-        // ---- phase 4: high rows, k-substep 1 ----
-        read_a(ra, a_rd1, FH);
-        if (more) {
-            if (needA) {
+                for (int i = 0; i < FH; ++i)
 #pragma unroll
-                for (int i = 2; i < NA; ++i) issue_a(i, la);
+                    for (int j = 0; j < FN; ++j) DT<T>::mma(fb[j], fal[i], acc[i0 + i][j]);             // A_lo x W_hi
+#pragma unroll
+                for (int i = 0; i < FH; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) DT<T>::mma(fbl[j], fa[i], acc[i0 + i][j]);             // A_hi x W_lo
+            } else {
+#pragma unroll
+                for (int i = 0; i < FH; ++i) {
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) DT<T>::mma(fbl[j], fa[i], acc[i0 + i][j]);             // A_hi x W_lo (row i), then a_lo[i] over a_hi[i]
+                    fa[i] = *reinterpret_cast<const u32x4*>(smem + b_ * BUF + a_rd1 + (i0 + i) * 2048);
+                }
+#pragma unroll
+                for (int i = 0; i < FH; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) DT<T>::mma(fb[j], fa[i], acc[i0 + i][j]);              // A_lo x W_hi
             }
-            advance();
-            // B and A-low of the next K tile have landed (this phase's A-high pieces, and the next output tile's 6 column-vector
-            // loads, may still be in flight)
-            if (PP_ABL == 9 && c_kt < 2) {}           // timing experiment: no wait in the two K tiles behind the stores (results garbage)
-            else if (!needA) pp_wait_vmcnt<0>();      // X3 T0: only B pieces were requested (phases 1-2); the loader never switches output tiles here
-            else if (switched) pp_wait_vmcnt<NA - 2 + (SPLIT ? 0 : 6)>();
-            else pp_wait_vmcnt<NA - 2>();
-        }
-        if (c_kt == nk - 1) {                         // last K tile of the output tile: its low rows are final since phase 3
-#ifdef PP_TRACE
-            if (tid == 0) pp_trace[blockIdx.x * 64 + 2 * ((c_tile - first) / G & 31)] = __builtin_amdgcn_s_memrealtime();
-#endif
-            store_rows(c_tile, I0_t{});               // (they restart in phase 1 of the next K tile)
-#ifdef PP_TRACE
-            if (tid == 0) pp_trace[blockIdx.x * 64 + 2 * ((c_tile - first) / G & 31) + 1] = __builtin_amdgcn_s_memrealtime();
-#endif
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        pp_barrier();
-        mfma_rows(I4_t{});
-        __builtin_amdgcn_sched_barrier(0);
-        pp_barrier();
+            if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        };
+        auto read_a_set = [&](int b_, int i0) {                // a_hi (, a_lo) of fragment rows i0 .. i0 + FH - 1
+            read_a(b_, a_rd0, i0);
+            if constexpr (KEEPA) {
+#pragma unroll
+                for (int i = 0; i < FH; ++i) fal[i] = *reinterpret_cast<const u32x4*>(smem + b_ * BUF + a_rd1 + (i0 + i) * 2048);
+            }
+        };
+        auto read_low_set = [&](int b_) {                      // phase L's fragments: the low rows' A set, w_hi and w_lo
+            read_a_set(b_, 0);
+            read_b(b_, b_rd0);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fbl[j] = *reinterpret_cast<const u32x4*>(smem + b_ * BUF + b_rd1 + j * 2048);
+        };
+        for (int s = 0; s < S; ++s) {
+            const bool more = s + 1 < S;              // another stage follows in this workgroup's stream: request it during this one
+            const int nb = buf ^ 1;
 
-        buf = nb;
-        if constexpr (X3) {
-            if (ty == 2) { ty = 0; cp ^= 1; } else ++ty;
+            // ---- phase L: low rows ----
+            __builtin_amdgcn_sched_barrier(0);
+            if (p_tile >= 0) {
+                // first stage of a new output tile (never the last stage of the stream: nk >= 2).  The previous tile's high rows, final since
+                // the phase-H MFMAs, leave now; its low rows left in that phase H.  VM queue, oldest first:
+                //   A-high of this stage | this tile's column vectors | low stores | high stores | W x FN | A-low x NAL     (see the bf16 loop below)
+                store_rows(p_tile, I4_t{});
+#pragma unroll
+                for (int i = 0; i < FN; ++i) issue_b(i, nb);
+                k_position();
+                issue_a(0, nb);
+                issue_a(1, nb);
+                pp_wait_vmcnt<FN + NAL + 2 * NST>();  // through A-high and the column vectors
+                init_rows(c_tile, I0_t{});
+                __builtin_amdgcn_sched_barrier(0);    // the fragment reads last: their registers are free for the epilogue's temporaries
+                read_low_set(buf);
+            } else {
+                read_low_set(buf);
+                if (more) {
+#pragma unroll
+                    for (int i = 0; i < FN; ++i) issue_b(i, nb);
+                    k_position();
+                    issue_a(0, nb);
+                    issue_a(1, nb);
+                    pp_wait_vmcnt<FN + NAL>();        // A-high of THIS stage (requested in phase H of the previous one) has landed
+                } else {
+                    pp_wait_vmcnt<0>();
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            pp_barrier();
+            mfma3(I0_t{}, buf);
+            __builtin_amdgcn_sched_barrier(0);
+            pp_barrier();
+
+            // ---- phase H: high rows ----  (tile-boundary work BEFORE the fragment reads: the A set's registers are free for its temporaries)
+            if (more) {
+#pragma unroll
+                for (int i = 2; i < NA; ++i) issue_a(i, nb);
+                advance();
+                // W and A-low of the next stage have landed (this phase's A-high pieces, and the next output tile's 6 column-vector loads, may fly)
+                if (switched) pp_wait_vmcnt<NAH + (SPLIT ? 0 : 6)>();
+                else pp_wait_vmcnt<NAH>();
+            }
+            if (p_tile >= 0) {                        // the high rows of the new tile start
+                init_rows(c_tile, I4_t{});
+                p_tile = -1;
+            }
+            if (c_kt == nk - 1) store_rows(c_tile, I0_t{});      // last stage of the output tile: its low rows are final since phase L (they restart in the next phase L)
+            __builtin_amdgcn_sched_barrier(0);
+            read_a_set(buf, FH);
+            __builtin_amdgcn_sched_barrier(0);
+            pp_barrier();
+            mfma3(I4_t{}, buf);
+            __builtin_amdgcn_sched_barrier(0);
+            pp_barrier();
+
+            buf = nb;
+            if (++c_kt == nk) {                       // output tile complete (high rows are stored in the next stage's phase L, or below)
+                p_tile = c_tile;
+                c_kt = 0;
+                c_tile += G;
+            }
         }
-        if (++c_kt == nk) {                           // output tile complete (high rows are stored in the next K tile's phase 2, or below)
-            p_tile = c_tile;
-            c_kt = 0;
-            c_tile += G;
+    } else {
+        for (int s = 0; s < S; ++s) {
+            const bool more = s + 1 < S;                  // another K tile follows in this workgroup's stream: request it during this one
+            const int nb = buf ^ 1;
+            const int ra = buf, rb = buf, la = nb, lb = nb;      // LDS buffers this K tile reads / the next one is staged into
+            const bool needA = more, needB = more;
+
+            // ---- phase 1: low rows, k-substep 0 ----
+            __builtin_amdgcn_sched_barrier(0);
+            if (p_tile < 0) {
+                read_a(ra, a_rd0, 0);
+                read_b(rb, b_rd0);
+            }
+            if (p_tile >= 0) {
+                // first K tile of a new output tile (never the last K tile of the stream: nk >= 2).  The previous tile's high rows, final
+                // since the phase-4 MFMAs, leave now; its low rows left in that phase 4.  The VM counter is in order and counts stores:
+                // a wait that only needs loads OLDER than the stores names the stores (and the residual loads behind them) as allowed
+                // in flight, so no wait of the K loop ever sits behind a store's round trip.  Queue, oldest first:
+                //   A-high of this K tile | next tile's column vectors | low stores | high stores | B x NB1
+                // (the residual loads of init_rows are the compiler's: it drains the counter at their first use)
+                store_rows(p_tile, I4_t{});
+#pragma unroll
+                for (int i = 0; i < NB1; ++i) issue_b(i, lb);
+                pp_wait_vmcnt<NB1 + 2 * NST>();           // through A-high
+                init_rows(c_tile, I0_t{});
+                __builtin_amdgcn_sched_barrier(0);        // the fragment reads last: their registers are free for the epilogue's temporaries
+                read_a(ra, a_rd0, 0);
+                read_b(rb, b_rd0);
+            } else if (needB) {
+#pragma unroll
+                for (int i = 0; i < NB1; ++i) issue_b(i, lb);
+                pp_wait_vmcnt<NB1>();                     // A-high of THIS K tile (requested in phase 4 of the previous one) has landed
+            } else {
+                pp_wait_vmcnt<0>();                       // last K tile of the stream
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            pp_barrier();
+            mfma_rows(I0_t{});
+            __builtin_amdgcn_sched_barrier(0);
+            pp_barrier();
+
+            // ---- phase 2: high rows, k-substep 0 ----
+            read_a(ra, a_rd0, FH);
+            if (needB) {
+#pragma unroll
+                for (int i = NB1; i < FN; ++i) issue_b(i, lb);
+            }
+            if (p_tile >= 0) {                            // the high rows of the new tile start
+                init_rows(c_tile, I4_t{});
+                p_tile = -1;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            pp_barrier();
+            mfma_rows(I4_t{});
+            __builtin_amdgcn_sched_barrier(0);
+            pp_barrier();
+
+            // ---- phase 3: low rows, k-substep 1 ----
+            read_a(ra, a_rd1, 0);
+            read_b(rb, b_rd1);
+            if (needA) {
+                k_position();
+                issue_a(0, la);
+                issue_a(1, la);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            pp_barrier();
+            mfma_rows(I0_t{});
+            __builtin_amdgcn_sched_barrier(0);
+            pp_barrier();
+
+            // ---- phase 4: high rows, k-substep 1 ----
+            read_a(ra, a_rd1, FH);
+            if (more) {
+                if (needA) {
+#pragma unroll
+                    for (int i = 2; i < NA; ++i) issue_a(i, la);
+                }
+                advance();
+                // B and A-low of the next K tile have landed (this phase's A-high pieces, and the next output tile's 6 column-vector
+                // loads, may still be in flight)
+                if (PP_ABL == 9 && c_kt < 2) {}           // timing experiment: no wait in the two K tiles behind the stores (results garbage)
+                else if (switched) pp_wait_vmcnt<NA - 2 + (SPLIT ? 0 : 6)>();
+                else pp_wait_vmcnt<NA - 2>();
+            }
+            if (c_kt == nk - 1) {                         // last K tile of the output tile: its low rows are final since phase 3
+#ifdef PP_TRACE
+                if (tid == 0) pp_trace[blockIdx.x * 64 + 2 * ((c_tile - first) / G & 31)] = __builtin_amdgcn_s_memrealtime();
+#endif
+                store_rows(c_tile, I0_t{});               // (they restart in phase 1 of the next K tile)
+#ifdef PP_TRACE
+                if (tid == 0) pp_trace[blockIdx.x * 64 + 2 * ((c_tile - first) / G & 31) + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            pp_barrier();
+            mfma_rows(I4_t{});
+            __builtin_amdgcn_sched_barrier(0);
+            pp_barrier();
+
+            buf = nb;
+            if (++c_kt == nk) {                           // output tile complete (high rows are stored in the next K tile's phase 2, or below)
+                p_tile = c_tile;
+                c_kt = 0;
+                c_tile += G;
+            }
         }
     }
     if (p_tile >= 0) store_rows(p_tile, I4_t{});

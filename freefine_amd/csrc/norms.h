@@ -8,16 +8,17 @@
 #pragma once
 #include "common.h"
 
-// PAIR output (split-bf16 mode, T = float): the normalised row is written as the bf16 pair [hi(C) | lo(C)] an FFN_BF16X3 GEMM reads as its
-// A operand (hi = bf16(v), lo = bf16(v - hi)) instead of fp32 -- same bytes, and the separate ffn_split_pair pass disappears.
+// PAIR output (split-bf16 mode, T = float): the normalised row is written in the bf16 pair form an FFN_BF16X3 GEMM reads as its A operand
+// (hi = bf16(v), lo = bf16(v - hi); blocked layout: common.h pair_pos) instead of fp32 -- same bytes, and the separate ffn_split_pair pass disappears.
 __device__ __forceinline__ void store_pair4(bf16* yp, long row, int C, int c, const float* f) {
     u32x2 hi, lo;
     hi[0] = pack_bf16x2(f[0], f[1]);
     hi[1] = pack_bf16x2(f[2], f[3]);
     lo[0] = pack_bf16x2(f[0] - __uint_as_float(hi[0] << 16), f[1] - __uint_as_float(hi[0] & 0xffff0000u));
     lo[1] = pack_bf16x2(f[2] - __uint_as_float(hi[1] << 16), f[3] - __uint_as_float(hi[1] & 0xffff0000u));
-    *reinterpret_cast<u32x2*>(yp + row * 2 * C + c) = hi;
-    *reinterpret_cast<u32x2*>(yp + row * 2 * C + C + c) = lo;
+    bf16* q = yp + row * 2 * C + pair_pos(c, C);
+    *reinterpret_cast<u32x2*>(q) = hi;
+    *reinterpret_cast<u32x2*>(q + pair_lo(C)) = lo;
 }
 
 // ---- (1) partial sums: grid (nchunk, B), 256 threads ------------------------------------------------------
@@ -240,8 +241,8 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const T* __restrict__ x,
             bf16* yp = reinterpret_cast<bf16*>(y);
             const long prow = ((long)b * HW + px) * 2 * C;
             const uint32_t hi = pack_bf16x2(a, d);
-            *reinterpret_cast<uint32_t*>(yp + prow + c) = hi;
-            *reinterpret_cast<uint32_t*>(yp + prow + C + c) = pack_bf16x2(a - __uint_as_float(hi << 16), d - __uint_as_float(hi & 0xffff0000u));
+            *reinterpret_cast<uint32_t*>(yp + prow + pair_pos(c, C)) = hi;
+            *reinterpret_cast<uint32_t*>(yp + prow + pair_pos(c, C) + pair_lo(C)) = pack_bf16x2(a - __uint_as_float(hi << 16), d - __uint_as_float(hi & 0xffff0000u));
         } else {
             DT<T>::st(y + off, a);
             DT<T>::st(y + off + 1, d);

@@ -103,15 +103,15 @@ def split_hi_lo(w):
 
 
 def pack_linear(w, dtype, x3=False):
-    """[N, K] -> [N, Kpad] zero padded, contiguous, dtype.  x3 (split-bf16, include/freefine_hip.h FFN_BF16X3): bf16 [N, 3K] =
-    [W_hi | W_lo | W_hi], the virtual contraction the kernels run against the activation's [A_hi | A_hi | A_lo]."""
+    """[N, K] -> [N, Kpad] zero padded, contiguous, dtype.  x3 (split-bf16, include/freefine_hip.h FFN_BF16X3): K % 32 == 0 -> the BLOCKED pair
+    form of every row, bf16 [N, 2K] = 128-byte blocks [W_hi(32) | W_lo(32)] (layout 2: what the ping-pong tile's split-bf16 core streams);
+    otherwise the planes bf16 [N, 3K] = [W_hi | W_lo | W_hi] (layout 1), the virtual contraction run against the activation's [A_hi | A_hi | A_lo]."""
     n, k = w.shape
     if x3:
         assert k % 8 == 0, f"split-bf16 weights need K % 8 == 0 (K={k})"
         hi, lo = split_hi_lo(w)
-        if k % 64 == 0:       # chunk order (what the ping-pong tile takes: each half tile staged once per chunk)
-            hc, lc = hi.reshape(n, k // 64, 64), lo.reshape(n, k // 64, 64)
-            return _mark_x3(torch.stack([hc, lc, hc], dim=2).reshape(n, 3 * k).contiguous(), 2)
+        if k % 32 == 0:
+            return _mark_x3(torch.stack([hi.reshape(n, k // 32, 32), lo.reshape(n, k // 32, 32)], dim=2).reshape(n, 2 * k).contiguous(), 2)
         return _mark_x3(torch.cat([hi, lo, hi], dim=1).contiguous(), 1)
     ks = kstage(dtype)
     kpad = (k + ks - 1) // ks * ks
@@ -121,7 +121,8 @@ def pack_linear(w, dtype, x3=False):
 
 
 def pack_conv3x3(w, dtype, cin_pad=None, x3=False):
-    """[Cout, Cin, 3, 3] -> [Cout, Kpad], k = (ky*3+kx)*Cin_p + ci  (x3: k' = ((ky*3+kx)*3 + seg)*Cin_p + ci, seg = hi, lo, hi)."""
+    """[Cout, Cin, 3, 3] -> [Cout, Kpad], k = (ky*3+kx)*Cin_p + ci  (x3: per tap the blocked pair form of its Cin_p columns, Cin_p % 32 == 0;
+    else k' = ((ky*3+kx)*3 + seg)*Cin_p + ci, seg = hi, lo, hi)."""
     cout, cin = w.shape[:2]
     cp = cin_pad or cin
     w2 = torch.zeros(cout, 3, 3, cp, dtype=torch.float32, device=w.device)
@@ -129,9 +130,8 @@ def pack_conv3x3(w, dtype, cin_pad=None, x3=False):
     if x3:
         assert cp % 8 == 0, f"split-bf16 conv weights need Cin % 8 == 0 (Cin={cp})"
         hi, lo = split_hi_lo(w2.reshape(cout, 9, cp))
-        if cp % 64 == 0:
-            hc, lc = hi.reshape(cout, 9, cp // 64, 64), lo.reshape(cout, 9, cp // 64, 64)
-            return _mark_x3(torch.stack([hc, lc, hc], dim=3).reshape(cout, 27 * cp).contiguous(), 2)
+        if cp % 32 == 0:
+            return _mark_x3(torch.stack([hi.reshape(cout, 9, cp // 32, 32), lo.reshape(cout, 9, cp // 32, 32)], dim=3).reshape(cout, 18 * cp).contiguous(), 2)
         return _mark_x3(torch.cat([hi, lo, hi], dim=2).reshape(cout, 27 * cp).contiguous(), 1)
     return pack_linear(w2.reshape(cout, 9 * cp), dtype)
 
@@ -147,7 +147,7 @@ def pack_conv3x3_up2x(w, dtype, x3=False):
     Output pixel (2y + a, 2x + b) sees the upsampled rows 2y + a - 1 .. 2y + a + 1 = low-resolution rows {y - 1, y, y} (a = 0) or {y, y, y + 1}
     (a = 1): a 2x2 window starting at (y + a - 1, x + b - 1) whose taps are sums of the 3x3 taps that coincide -- 4/9 of the multiplies.
     Rows [c Cout, (c + 1) Cout) hold class c = 2a + b, k = (dy*2 + dx) Cin + ci.  The sums are taken in fp32 and rounded once.
-    x3 (split-bf16 mode, Cin % 64 == 0): the chunk-ordered [hi | lo | hi] form of pack_conv3x3 over the four taps."""
+    x3 (split-bf16 mode, Cin % 32 == 0): the blocked pair form of pack_conv3x3 over the four taps."""
     assert dtype == torch.bfloat16 or x3
     cout, cin = w.shape[:2]
     wf = w.float()
@@ -163,10 +163,9 @@ def pack_conv3x3_up2x(w, dtype, x3=False):
                             acc += wf[:, :, ky, kx]
                     out[2 * a + b, :, dy, dx] = acc
     if x3:
-        assert cin % 64 == 0
+        assert cin % 32 == 0
         hi, lo = split_hi_lo(out.reshape(4 * cout, 4, cin))
-        hc, lc = hi.reshape(4 * cout, 4, cin // 64, 64), lo.reshape(4 * cout, 4, cin // 64, 64)
-        return _mark_x3(torch.stack([hc, lc, hc], dim=3).reshape(4 * cout, 12 * cin).contiguous(), 2)
+        return _mark_x3(torch.stack([hi.reshape(4 * cout, 4, cin // 32, 32), lo.reshape(4 * cout, 4, cin // 32, 32)], dim=3).reshape(4 * cout, 8 * cin).contiguous(), 2)
     return pack_linear(out.reshape(4 * cout, 4 * cin), dtype)
 
 
@@ -196,7 +195,7 @@ def conv3x3_up2x(x, w4, bias, B, Hin, Win, Cin, *, out=None):
     else:
         assert x.dtype == torch.bfloat16 and x.is_contiguous()
         xa, odt, dcode = x, x.dtype, L.FFN_BF16
-    assert w4.shape[1] >= (12 if x3 else 4) * Cin
+    assert w4.shape[1] >= (8 if x3 else 4) * Cin
     y = torch.empty(B, Hin * Win, 4 * cout, dtype=odt, device=x.device)
     for c in range(4):
         a, b = c >> 1, c & 1
@@ -204,7 +203,7 @@ def conv3x3_up2x(x, w4, bias, B, Hin, Win, Cin, *, out=None):
         d.A, d.W = xa.data_ptr(), w4.data_ptr() + c * cout * w4.stride(0) * w4.element_size()
         d.bias, d.rowbias, d.residual = _p(bias), None, None
         d.M, d.N, d.K, d.Kpad = B * Hin * Win, cout, 4 * Cin, w4.stride(0)
-        d.lda, d.a_lo, d.x3 = (2 * Cin, Cin, 2) if x3 else (Cin, 0, 0)
+        d.lda, d.a_lo, d.x3 = (2 * Cin, 32, 2) if x3 else (Cin, 0, 0)
         d.rows_per_batch, d.ldrb = Hin * Win, 0
         d.out, d.ldo, d.ldr = y.data_ptr() + c * cout * y.element_size(), 4 * cout, 0
         d.Hin, d.Win, d.Cin, d.Hout, d.Wout = Hin, Win, Cin, Hin, Win
@@ -273,7 +272,7 @@ def pack_geglu(w, b, dtype, x3=False):
 
 
 def _mark_pair(t, C):
-    t._ffn_pair = C            # bf16 [..., 2C] = [hi(C) | lo(C)]: the A operand of an FFN_BF16X3 GEMM
+    t._ffn_pair = C            # bf16 [..., 2C]: the pair form of rows of C fp32 values (C % 32 == 0: 128-byte blocks [hi(32) | lo(32)]; else planes): the A operand of an FFN_BF16X3 GEMM
     return t
 
 
@@ -283,7 +282,7 @@ def pair_width(x):
 
 
 def split_pair(x, K=None):
-    """fp32 [..., ld] (first K columns) -> bf16 PAIR rows [..., 2K] = [hi | lo] (ffn_split_pair): the A operand of an FFN_BF16X3 GEMM"""
+    """fp32 [..., ld] (first K columns) -> bf16 PAIR rows [..., 2K] (ffn_split_pair; layout: include/freefine_hip.h FFN_BF16X3): the A operand of an FFN_BF16X3 GEMM"""
     lib = L.load()
     assert x.dtype == torch.float32 and x.stride(-1) == 1
     K = K if K is not None else x.shape[-1]
@@ -330,8 +329,8 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
     d.bias, d.rowbias, d.residual = _p(bias), _p(rowbias), _p(residual)
     d.M, d.N, d.K, d.Kpad = M, N, K, w.stride(0)    # Kpad = row stride of W (an activation view can serve as W)
     d.lda = xa.stride(-2) if xa.ndim > 1 else xa.shape[-1]
-    d.a_lo = K if x3 else 0
     d.x3 = int(w._ffn_x3) if x3 else 0
+    d.a_lo = (32 if d.x3 == 2 else K) if x3 else 0          # blocked pair rows (K % 32 == 0) / planes
     odt = torch.float32 if x3 else x.dtype          # element type of out / residual
     d.rows_per_batch = rows_per_batch or M
     d.ldrb = rowbias.stride(0) if rowbias is not None else 0
@@ -406,8 +405,8 @@ def conv3x3(x, w, bias, B, Hin, Win, Cin, *, stride=1, pad=1, upsample=False, ou
     d.bias, d.rowbias, d.residual = _p(bias), _p(rowbias), _p(residual)
     d.M, d.N, d.K, d.Kpad = B * Hout * Wout, N, 9 * Cin, w.shape[1]
     d.lda = 2 * Cin if x3 else Cin
-    d.a_lo = Cin if x3 else 0
     d.x3 = int(w._ffn_x3) if x3 else 0
+    d.a_lo = (32 if d.x3 == 2 else Cin) if x3 else 0
     d.rows_per_batch = Hout * Wout
     d.ldrb = (rowbias_ld or rowbias.stride(0)) if rowbias is not None else 0
     if out is None:

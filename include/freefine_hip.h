@@ -47,8 +47,8 @@ enum {
     FFN_IG_OUT_F32 = 1 << 1,
     FFN_IG_GEGLU = 1 << 2,         /* N = 2*Nout; 16-column blocks alternate hidden/gate; out = hidden * gelu(gate) */
     FFN_IG_OUT_TRANSPOSED = 1 << 3, /* out[b][n][s], row stride ldo, m = b*rows_per_batch + s (V^T for ffn_attn) */
-    FFN_IG_OUT_PAIR = 1 << 4,       /* FFN_BF16X3 only: out is the bf16 PAIR form [M][ldo], hi at column n, lo at column ldo/2 + n -- the A operand
-                                       of the next FFN_BF16X3 GEMM (the GEGLU projection feeding ff.net.2); no residual */
+    FFN_IG_OUT_PAIR = 1 << 4,       /* FFN_BF16X3 only: out is the bf16 PAIR form [M][ldo] of rows of C = ldo/2 columns (layout: FFN_BF16X3 below) -- the A
+                                       operand of the next FFN_BF16X3 GEMM (the GEGLU projection feeding ff.net.2); no residual */
     FFN_IG_OUT_GELU = 1 << 5,       /* out = gelu_erf(acc + bias) (+ residual): the MLP of the DINOv2 blocks (dinov2/layers/mlp.py:31-38) */
     FFN_IG_OUT_RELU = 1 << 6        /* out = max(acc + bias, 0) (+ residual): the DPT head's ResidualConvUnit / output convs (depth_anything/blocks.py:68-78,
                                        dpt.py:93-98).  SILU / GELU / RELU are mutually exclusive and exclude GEGLU and the transposed output */
@@ -73,9 +73,10 @@ typedef struct ffn_igemm_desc {
     int splitk;       /* 0 = let the library choose (needs ws), 1 = never split, k = force k K-slices */
     void* ws;         /* optional fp32 scratch for split-K partial slabs (>= splitk*M*N*4 bytes) or NULL */
     long ws_bytes;
-    int a_lo;         /* FFN_BF16X3: column (conv: channel) offset of the lo plane inside a row (pixel) of A; else ignored */
-    int x3;           /* FFN_BF16X3: order of W's virtual contraction -- 0 / 1 = plane order [W_hi | W_lo | W_hi] over the whole K (conv: tap);
-                         2 = chunk order: that triple per 64-element chunk (needs K, conv: Cin, % 64 == 0; what the ping-pong tile takes) */
+    int a_lo;         /* FFN_BF16X3: x3 = 0 / 1: column (conv: channel) offset of the lo plane inside a row (pixel) of A; x3 = 2: 32 (the block); else ignored */
+    int x3;           /* FFN_BF16X3: operand layout -- 0 / 1 = planes (A [hi(K) | lo(K)], W [W_hi | W_lo | W_hi] over the whole K, conv: per tap);
+                         2 = blocked: A and W as 128-byte blocks [hi(32) | lo(32)] per 32 elements of K (needs K, conv: Cin, % 32 == 0; what the
+                         ping-pong tile's split-bf16 core streams) */
     int f8;           /* set by the library from `dtype` (callers leave it 0) */
 } ffn_igemm_desc;
 int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
@@ -83,10 +84,14 @@ int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
  * lo = bf16(v - hi) (16-17 significant bits together) and a product a*w is evaluated as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the bf16
  * MFMA with fp32 accumulation -- 3 MFMAs per product term (ceiling 2.5 PFLOP/s / 3 = 833 TFLOP/s against 157 TFLOP/s of the fp32
  * MFMA), dropped term a_lo*w_lo ~ 2^-18.  Operand formats:
- *   A    bf16 PAIR rows: hi plane at columns [0, K), lo plane at [a_lo, a_lo + K) of the same row (lda = row stride in bf16
- *        elements; conv: per input pixel, planes of Cin channels, lda = elements per pixel) -- ffn_split_pair writes it from fp32;
- *   W    bf16 [N][Kpad], Kpad >= 3K: [W_hi | W_lo | W_hi] (conv: that triple per tap, k' = (tap*3 + seg)*Cin + ci) -- or, desc.x3 = 2,
- *        the triple per 64-element chunk (k' = ((tap*Cin/64 + chunk)*3 + seg)*64 + e), which the ping-pong kernel needs;
+ *   the PAIR form of a row (pixel) of C fp32 values = 2C bf16.  C % 32 == 0: BLOCKED -- every 32 columns are one 128-byte block
+ *        [hi(32) | lo(32)] (column c: hi at element 64 (c / 32) + c % 32, lo 32 elements behind it), so that a 32-deep K stage of a GEMM is
+ *        ONE whole line carrying both planes (round 5; rounds 3-4 kept two planes and streamed the hi plane twice).  Otherwise one block of C
+ *        columns, i.e. the planes [hi(C) | lo(C)].  ffn_split_pair, the *_pair norms, FFN_IG_OUT_PAIR and ffn_attn's out_pair all write it;
+ *   A    pair rows of K columns (conv: pixels of Cin channels), lda = row (pixel) stride in bf16 elements.  desc.x3 = 2 (blocked, K resp.
+ *        Cin % 32 == 0): a_lo = 32.  desc.x3 = 0 / 1 (planes): lo plane at columns [a_lo, a_lo + K);
+ *   W    bf16 [N][Kpad].  x3 = 2: the pair form of each fp32 weight row, conv: of each tap's Cin columns (Kpad >= 2K; column
+ *        k' = (tap*Cin/32 + block)*64 + {0, 32} + e).  x3 = 0 / 1: Kpad >= 3K, [W_hi | W_lo | W_hi] (conv: per tap, k' = (tap*3 + seg)*Cin + ci);
  *   out, residual   fp32 (FFN_IG_OUT_F32 is implied); bias / rowbias fp32 as always; GEGLU, SILU, transposed output, split-K as in bf16.
  * K in the descriptor is the REAL contraction length (dense K, conv 9*Cin). */
 int ffn_split_pair(void* stream, const float* src, void* dst, long rows, int C, int ld_src);
@@ -159,7 +164,7 @@ typedef struct ffn_attn_desc {
     int ldq, ldk, ldvt, ldo;
     float scale;
     int npass;
-    int out_pair;       /* FFN_BF16X3 with D <= 64 only: out is the bf16 PAIR form [Bo][S][ldo] (hi at column c, lo at ldo/2 + c), the A operand of
+    int out_pair;       /* FFN_BF16X3 with D <= 64 only: out is the bf16 PAIR form [Bo][S][ldo] of rows of ldo/2 columns (layout: FFN_BF16X3 above), the A operand of
                            the to_out projection's FFN_BF16X3 GEMM; 0 = fp32 rows */
     int reserved;
     ffn_attn_entry e[FFN_ATT_MAXP * FFN_ATT_MAXB]; /* entry (p,b) at p*FFN_ATT_MAXB + b */
@@ -214,7 +219,7 @@ int ffn_splat_render(void* stream, const float* proj, const float* rgb, const in
 
 /* ---- normalisation ------------------------------------------------------------------------------------------- */
 /* `silu` of ffn_groupnorm / ffn_gn_apply is a flag word: FFN_NORM_SILU applies SiLU; FFN_NORM_OUT_PAIR (fp32 input only) writes y as the
- * bf16 PAIR rows [B*HW][2C] = [hi | lo] an FFN_BF16X3 GEMM reads (no separate ffn_split_pair pass).  ffn_layernorm_pair: the same for LayerNorm. */
+ * bf16 PAIR rows [B*HW][2C] an FFN_BF16X3 GEMM reads (layout: FFN_BF16X3 above; no separate ffn_split_pair pass).  ffn_layernorm_pair: the same for LayerNorm. */
 enum { FFN_NORM_SILU = 1, FFN_NORM_OUT_PAIR = 2 };
 /* GroupNorm statistics -> per-(batch,channel) scale/shift (fp32).  partial_ws: >= B*nchunk*2*C floats where
  * nchunk = ffn_gn_nchunk(HW).  Replaces torch GroupNorm inside diffusers blocks (attention.py:105-214). */

@@ -19,6 +19,14 @@ def relerr(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
 
+def pair_value(p, C):
+    """hi + lo of split-bf16 pair rows [..., 2C] (include/freefine_hip.h FFN_BF16X3: 128-byte blocks [hi(32) | lo(32)] when C % 32 == 0, else planes)"""
+    if C % 32 == 0:
+        b = p.double().reshape(*p.shape[:-1], C // 32, 2, 32)
+        return (b[..., 0, :] + b[..., 1, :]).reshape(*p.shape[:-1], C)
+    return p[..., :C].double() + p[..., C:].double()
+
+
 def tol(dtype):
     return 2e-5 if dtype == torch.float32 else 1.5e-2
 
@@ -731,10 +739,17 @@ def test_x3_split_pair(gpu):
     x = (torch.randn(37, 328, generator=g) * torch.logspace(-3, 3, 328)).to(gpu)
     p = ops.split_pair(x, 320)
     assert p.shape == (37, 640) and p.dtype == torch.bfloat16
-    hi, lo = p[:, :320].float(), p[:, 320:].float()
+    # C % 32 == 0: the BLOCKED pair form -- 128-byte blocks [hi(32) | lo(32)] per 32 columns (include/freefine_hip.h FFN_BF16X3)
+    blk = p.view(37, 10, 2, 32)
+    hi, lo = blk[:, :, 0].reshape(37, 320).float(), blk[:, :, 1].reshape(37, 320).float()
     assert torch.equal(hi, x[:, :320].to(torch.bfloat16).float())
     assert torch.equal(lo, (x[:, :320] - hi).to(torch.bfloat16).float())
     assert ((hi + lo - x[:, :320]).abs() <= x[:, :320].abs() * 2.0 ** -16).all()
+    # any other width: one block of C columns = the planes [hi(C) | lo(C)]
+    p = ops.split_pair(x, 72)
+    assert p.shape == (37, 144)
+    hi, lo = p[:, :72].float(), p[:, 72:].float()
+    assert torch.equal(hi, x[:, :72].to(torch.bfloat16).float()) and torch.equal(lo, (x[:, :72] - hi).to(torch.bfloat16).float())
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 320, 320), (4096, 1280, 320), (77 * 4, 640, 1024), (4, 1280, 320), (1000, 4, 320), (16384, 320, 1280),
@@ -748,7 +763,7 @@ def test_x3_linear(gpu, M, N, K):
     b = torch.randn(N, generator=g).to(gpu)
     res = rnd((M, N), dt, gpu, g)
     wp = ops.pack_linear(w, dt, x3=True)
-    assert ops.is_x3(wp) and wp.shape == (N, 3 * K) and wp.dtype == torch.bfloat16
+    assert ops.is_x3(wp) and wp.shape == (N, (2 if K % 32 == 0 else 3) * K) and wp.dtype == torch.bfloat16
     ref = x.double() @ w.double().t() + b.double()
     out = ops.linear(x, wp, b, K=K)
     assert out.dtype == torch.float32
@@ -821,7 +836,7 @@ def test_x3_conv3x3(gpu, cfg):
     res = rnd((B, Ho * Wo, Cout), dt, gpu, g)
     x_nhwc = x.permute(0, 2, 3, 1).reshape(B, H * W, Cin).contiguous()
     wp = ops.pack_conv3x3(w, dt, x3=True)
-    assert wp.shape == (Cout, 27 * Cin)
+    assert wp.shape == (Cout, (18 if Cin % 32 == 0 else 27) * Cin)
     ref_nhwc = ref.permute(0, 2, 3, 1).reshape(B, Ho * Wo, Cout)
     out = ops.conv3x3(x_nhwc, wp, b, B, H, W, Cin, stride=cfg["stride"], pad=1, upsample=cfg["up"], Hout=Ho, Wout=Wo)
     e0 = relerr(out, ref_nhwc)
@@ -986,7 +1001,7 @@ def test_x3_attention_pingpong_schedule(gpu, S, Sk, heads):
     assert max(errs) < X3_TOL
     pair = ops.attention(q, k, vt, heads, scale, [p0, p1], Sk=Sk, w_dev=cg, x3=True, out_pair=True)
     assert pair.dtype == torch.bfloat16 and pair.shape == (B, S, 2 * Cc)
-    assert relerr(pair[..., :Cc].double() + pair[..., Cc:].double(), out.double()) < 2e-5
+    assert relerr(pair_value(pair, Cc), out.double()) < 2e-5
     for _ in range(3):
         assert torch.equal(ops.attention(q, k, vt, heads, scale, [p0, p1], Sk=Sk, w_dev=cg, x3=True), out)
 
