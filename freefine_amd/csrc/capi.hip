@@ -14,6 +14,7 @@
 #include "attention_x.h"
 #include "attention_x3.h"
 #include "attention_x3p.h"
+#include "attention_xx3.h"
 #include "elementwise.h"
 #include "igemm.h"
 #include "igemm_p8.h"
@@ -537,7 +538,8 @@ static int candidates_for(const ffn_igemm_desc& d, IgChoice* out, int cap) {
             // output tiles alone leave most of the chip idle
             const long pt = (long)((d.M + c.bm - 1) / c.bm) * (d.N / (c.bn > 0 ? c.bn : 1));
             if (d.splitk <= 1 && pp_ok(d, c.bm, c.bn) && n < cap) out[n++] = IgChoice{cfg, 1};
-            if (d.splitk != 1 && pt > 0 && pt < 160 && d.N % c.bn == 0) {
+            static const int split_below = [] { const char* e = getenv("FFN_PP_SPLIT_BELOW"); return e ? atoi(e) : 160; }();      // unsplit tile counts below this get split-K candidates
+            if (d.splitk != 1 && pt > 0 && pt < split_below && d.N % c.bn == 0) {
                 const int nkt = d.x3 ? d.K / 96 : d.K / 64;
                 int added = 0;
                 for (int sgo = (int)((384 + pt - 1) / pt); sgo >= 2 && added < 2; --sgo) {
@@ -719,6 +721,10 @@ extern "C" int ffn_igemm_kernel_name(int dtype, const ffn_igemm_desc* d0, char* 
     const ffn_igemm_desc dd = x3 ? x3_view(*d0) : (f8 ? f8_view(*d0) : *d0);
     const ffn_igemm_desc* d = &dd;
     if (x3 && (d->flags & FFN_IG_OUT_TRANSPOSED)) {
+        if (!d->conv && pp_trans_tile(*d, &bm, &bn)) {
+            snprintf(buf, len, "void igemm_pp_kernel<%d, %d, 0, false, false, false, true, true, false>(ffn_igemm_desc, int)", bm, bn);
+            return FFN_OK;
+        }
         igemm_plan_for(FFN_BF16, *d, &bm, &bn, &sk);
         snprintf(buf, len, "void igemm_glds_kernel<bf16, %d, %d, 0, false, 2, 2, 2, false, true, false>(ffn_igemm_desc)", bm, bn);
         return FFN_OK;
@@ -764,9 +770,12 @@ static bool pp_trans_tile(const ffn_igemm_desc& d, int* bm, int* bn) {
     if (!on) return false;
     const long lim = (1l << 31) - 4096;
     *bn = d.N % 320 == 0 ? 320 : (d.N % 256 == 0 ? 256 : 0);
-    if (!*bn || d.K % 64 != 0 || d.K < 128 || d.alpha != 1.0f || d.rows_per_batch % 16 != 0 || d.M % 4 != 0) return false;
+    if (!*bn || d.alpha != 1.0f || d.rows_per_batch % 16 != 0 || d.M % 4 != 0) return false;
+    if (d.x3) {         // split-bf16: blocked operands, K tiles of 32 real elements (d.K = the virtual 3 K), fp32 V^T
+        if (d.x3 != 2 || d.K % 96 != 0 || d.K < 192 || d.a_lo != 32) return false;
+    } else if (d.K % 64 != 0 || d.K < 128) return false;
     if ((long)(d.M + 256) * d.lda * 2 >= lim || (long)d.N * d.Kpad * 2 >= lim) return false;
-    if ((long)((d.M + d.rows_per_batch - 1) / d.rows_per_batch) * d.N * d.ldo * 2 >= lim) return false;
+    if ((long)((d.M + d.rows_per_batch - 1) / d.rows_per_batch) * d.N * d.ldo * (d.x3 ? 4 : 2) >= lim) return false;
     long best = -1;
     for (int h : {256, 192}) {
         if (d.M < h) continue;
@@ -776,6 +785,7 @@ static bool pp_trans_tile(const ffn_igemm_desc& d, int* bm, int* bn) {
     }
     return best >= 0;
 }
+template <bool X3 = false>
 static int launch_pp_trans(hipStream_t s, const ffn_igemm_desc& d, int bm, int bn) {
     const int pplds = 2 * (bm + bn) * 128 + 12288;
     const int nt = ((d.M + bm - 1) / bm) * (d.N / bn);
@@ -784,7 +794,7 @@ static int launch_pp_trans(hipStream_t s, const ffn_igemm_desc& d, int bm, int b
     (void)hipGetLastError();
 #define FFN_PP_TR(BM_, BN_)                                                                         \
     do {                                                                                            \
-        auto kern = igemm_pp_kernel<BM_, BN_, AMODE_DENSE, false, false, false, true>;              \
+        auto kern = igemm_pp_kernel<BM_, BN_, AMODE_DENSE, false, false, false, true, X3>;          \
         if ((rc = set_lds(kern, pplds))) return rc;                                                 \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pplds, s, d, 1);                            \
     } while (0)
@@ -833,8 +843,9 @@ static int dispatch_igemm_x3(hipStream_t s, const ffn_igemm_desc& d) {
         if (tr) return fail(FFN_EINVAL, "igemm: transposed output is only supported for dense A");
         return tuned_bf16<AMODE_CONV3, true>(s, d);
     }
-    if (tr) {            // V^T for the attention kernels: generic tile, fp32 transposed stores
+    if (tr) {            // V^T for the attention kernels, fp32 transposed stores: the ping-pong tile where it applies, else a generic tile
         int bm, bn, sk;
+        if (pp_trans_tile(d, &bm, &bn)) return launch_pp_trans<true>(s, d, bm, bn);
         igemm_plan_for(FFN_BF16, d, &bm, &bn, &sk);
         if (bm == 128 && bn == 128) return launch_x3_trans<128, 128>(s, d);
         if (bm == 128) return launch_x3_trans<128, 64>(s, d);
@@ -983,9 +994,10 @@ static void attn_bf16_choice(const ffn_attn_desc& d, bool* masks, bool* pp) {
 // cross attention against a short key sequence (attention_x.h): bf16, d = 64, Sk <= 96, ONE pass whose entries are all active and carry
 // no mask / selector / per-query weight.  Returns the key-fragment count of the instantiation (0: not this kernel).
 // *multi = 1: the launch has several passes, skipped entries or per-query weights -> xattn_mp_kernel (K / V^T fragment images in LDS).
-static int xattn_nkf(const ffn_attn_desc& d, int* multi = nullptr) {
+// esz = bytes per operand element: 2 (bf16 kernels) or 4 (xattn_x3_kernel, attention_xx3.h: fp32 operands in split-bf16 arithmetic)
+static int xattn_nkf(const ffn_attn_desc& d, int* multi = nullptr, int esz = 2) {
     static const bool on = [] { const char* e = getenv("FFN_ATTN_X"); return !(e && atoi(e) == 0); }();
-    if (!on || d.D != 64 || d.Sk > 96 || d.ldo % 8 != 0) return 0;
+    if (!on || d.D != 64 || d.Sk > 96 || (esz == 2 && d.ldo % 8 != 0)) return 0;
     int maxq = 0, maxkv = 0, mp = d.npass != 1;
     for (int pi = 0; pi < d.npass; ++pi)
         for (int b = 0; b < d.Bo; ++b) {
@@ -999,8 +1011,8 @@ static int xattn_nkf(const ffn_attn_desc& d, int* multi = nullptr) {
         }
     if (multi) *multi = mp;
     const long lim = (1l << 31) - 65536;              // 32-bit byte offsets into every operand
-    if ((long)(maxq + 1) * d.S * d.ldq * 2 >= lim || (long)d.Bo * d.S * d.ldo * 2 >= lim || (long)(maxkv + 1) * d.Sk * d.ldk * 2 >= lim ||
-        (long)(maxkv + 1) * d.heads * 64 * d.ldvt * 2 >= lim)
+    if ((long)(maxq + 1) * d.S * d.ldq * esz >= lim || (long)d.Bo * d.S * d.ldo * esz >= lim || (long)(maxkv + 1) * d.Sk * d.ldk * esz >= lim ||
+        (long)(maxkv + 1) * d.heads * 64 * d.ldvt * esz >= lim)
         return 0;
     const int need = (d.Sk + 15) / 16;
     return need <= 2 ? 2 : (need <= 5 ? 5 : 6);
@@ -1033,6 +1045,25 @@ static int launch_xattn(hipStream_t s, const ffn_attn_desc& d, int nkf, int mult
     else LAUNCH(xattn_kernel<6>, grid, dim3(256), 0, s, d, wpp, bpw);
     return check_launch("attn(cross)");
 }
+// the split-bf16 form: always the LDS-fragment-image structure (hi and lo images of every active pass: 2 x nfr KiB per pass)
+static int launch_xattn_x3(hipStream_t s, const ffn_attn_desc& d, int nkf) {
+    const int pairs = d.Bo * d.heads, nblk = (d.S + 31) / 32;
+    int wpp = (8 * device_cus()) / pairs / 4;         // workgroups per (row, head)
+    if (wpp < 1) wpp = 1;
+    if (wpp > (nblk + 3) / 4) wpp = (nblk + 3) / 4;
+    const int bpw = (nblk + 4 * wpp - 1) / (4 * wpp);
+    wpp = (nblk + 4 * bpw - 1) / (4 * bpw);
+    const int nfr = nkf * 2 + 4 * ((nkf + 1) / 2);
+    const int lds = d.npass * 2 * nfr * 1024;
+    if (lds > 160 * 1024) return -1;                  // (more passes than fit: the caller takes the generic kernel)
+    dim3 grid(pairs * wpp);
+    int rc;
+    if (nkf == 2) { if ((rc = set_lds(xattn_x3_kernel<2>, lds))) return rc; LAUNCH(xattn_x3_kernel<2>, grid, dim3(256), lds, s, d, wpp, bpw); }
+    else if (nkf == 5) { if ((rc = set_lds(xattn_x3_kernel<5>, lds))) return rc; LAUNCH(xattn_x3_kernel<5>, grid, dim3(256), lds, s, d, wpp, bpw); }
+    else { if ((rc = set_lds(xattn_x3_kernel<6>, lds))) return rc; LAUNCH(xattn_x3_kernel<6>, grid, dim3(256), lds, s, d, wpp, bpw); }
+    return check_launch("attn(cross, split-bf16)");
+}
+static bool xattn_x3_fits(const ffn_attn_desc& d, int nkf) { return d.npass * 2 * (nkf * 2 + 4 * ((nkf + 1) / 2)) * 1024 <= 160 * 1024; }
 static bool attn_has_masks(const ffn_attn_desc& d) {
     for (int pi = 0; pi < d.npass; ++pi)
         for (int b = 0; b < d.Bo; ++b) {
@@ -1045,6 +1076,12 @@ extern "C" int ffn_attn_kernel_name(int dtype, const ffn_attn_desc* d, char* buf
     REQUIRE(d && buf && len > 0, "attn_kernel_name: null argument");
     int dp = 0, qf = 0;
     if (dtype == FFN_BF16X3 && d->D <= 64) {
+        if (const int nkf = xattn_nkf(*d, nullptr, 4)) {
+            if (xattn_x3_fits(*d, nkf)) {
+                snprintf(buf, len, "void xattn_x3_kernel<%d>(ffn_attn_desc, int, int)", nkf);
+                return FFN_OK;
+            }
+        }
         bool masks, pp;
         attn_bf16_choice(*d, &masks, &pp);
         snprintf(buf, len, "void %s<%s>(ffn_attn_desc)", pp ? "attn_x3p_kernel" : "attn_x3_kernel", attn_has_masks(*d) ? "true" : "false");
@@ -1083,6 +1120,9 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int D = d->D;
     if (dtype == FFN_BF16X3 && D <= 64) {      // split-bf16 arithmetic on fp32 operands (attention_x3.h); other head sizes: the exact fp32 kernel
+        if (const int nkf = xattn_nkf(*d, nullptr, 4)) {       // short unmasked key sequences (the text cross attention): attention_xx3.h
+            if (xattn_x3_fits(*d, nkf)) return launch_xattn_x3(s, *d, nkf);
+        }
         constexpr int lds = 2 * (4 * 8192) + 8 * 4 * 2 * 64 * 16;
         dim3 grid(((d->S + 255) / 256) * d->heads * d->Bo);
         int rc;

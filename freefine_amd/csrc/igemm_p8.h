@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     const int lrow = lane >> 3, csrc = (lane & 7) ^ lrow;
 
     static_assert(!SPLIT || (!RES && !GEGLU), "split-K slabs carry raw accumulators: the epilogue runs in the reduce kernel");
-    static_assert(!TRANS || (!RES && !GEGLU && !SPLIT && !X3 && AMODE == AMODE_DENSE), "transposed output: dense A, bias only");
+    static_assert(!TRANS || (!RES && !GEGLU && !SPLIT && AMODE == AMODE_DENSE), "transposed output: dense A, bias only");
     static_assert(!F8 || (!X3 && !TRANS && !GEGLU), "fp8 operands: plain / residual / split-K epilogues");
     const int ntn = p.N / BN;
     const int ntm = (p.M + BM - 1) / BM;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     const int nbatch = (p.M + p.rows_per_batch - 1) / p.rows_per_batch;
     const __amdgpu_buffer_rsrc_t rsrcRb =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.rowbias), 0, p.rowbias ? ((nbatch - 1) * p.ldrb + p.N) * 4 : 0, 0x00020000);
-    const long o_bytes = TRANS ? (long)((p.M + p.rows_per_batch - 1) / p.rows_per_batch) * p.N * p.ldo * 2 : (long)p.M * p.ldo * OSZ;
+    const long o_bytes = TRANS ? (long)((p.M + p.rows_per_batch - 1) / p.rows_per_batch) * p.N * p.ldo * OSZ : (long)p.M * p.ldo * OSZ;
     const __amdgpu_buffer_rsrc_t rsrcO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)o_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, RES ? (int)((long)p.M * p.ldr * OSZ) : 0, 0x00020000);
 
@@ -439,13 +439,19 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
             return;
         }
         if constexpr (TRANS) {                        // out[(b * N + n) * ldo + s], four consecutive s per lane (rows_per_batch % 16 == 0)
-            const int voff = (pr * p.ldo + 4 * pg) * 2;
+            const int voff = (pr * p.ldo + 4 * pg) * OSZ;
 #pragma unroll
             for (int i = i0; i < i0 + FH; ++i) {
                 const int mb = m0 + i * 16;
                 const int bb = mb / p.rows_per_batch, sb = mb - bb * p.rows_per_batch;
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
+                    if constexpr (X3) {               // fp32 V^T (the split-bf16 attention kernels read fp32 operands): 16 bytes per lane
+                        u32x4 w4 = __builtin_bit_cast(u32x4, acc[i][j]);
+                        w4[0] = perm(w4[0]); w4[1] = perm(w4[1]); w4[2] = perm(w4[2]); w4[3] = perm(w4[3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(w4, rsrcO, mb + 4 * pg < p.M ? voff : OOB, ((bb * p.N + n0 + j * 16) * p.ldo + sb) * 4, 0);
+                        continue;
+                    }
                     u32x2 w;
                     w[0] = perm(pack_bf16x2(acc[i][j][0], acc[i][j][1]));
                     w[1] = perm(pack_bf16x2(acc[i][j][2], acc[i][j][3]));
@@ -471,8 +477,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
                     const int vo2 = m0 + i * 16 + pr < p.M ? (pr * p.ldo + 4 * pg) * 2 : OOB;
 #pragma unroll
                     for (int j = 0; j + 1 < FN; j += 2) {
-                        const f32x2_t g01 = gelu_erf26_2(f32x2_t{acc[i][j + 1][0], acc[i][j + 1][1]}) * f32x2_t{acc[i][j][0], acc[i][j][1]};
-                        const f32x2_t g23 = gelu_erf26_2(f32x2_t{acc[i][j + 1][2], acc[i][j + 1][3]}) * f32x2_t{acc[i][j][2], acc[i][j][3]};
+                        const f32x2_t g01 = (PP_ABL == 3 ? f32x2_t{acc[i][j + 1][0], acc[i][j + 1][1]} : gelu_erf26_2(f32x2_t{acc[i][j + 1][0], acc[i][j + 1][1]})) * f32x2_t{acc[i][j][0], acc[i][j][1]};
+                        const f32x2_t g23 = (PP_ABL == 3 ? f32x2_t{acc[i][j + 1][2], acc[i][j + 1][3]} : gelu_erf26_2(f32x2_t{acc[i][j + 1][2], acc[i][j + 1][3]})) * f32x2_t{acc[i][j][2], acc[i][j][3]};
                         const float v[4] = {g01[0], g01[1], g23[0], g23[1]};
                         u32x2 hi, lo;
                         hi[0] = pack_bf16x2(v[0], v[1]);
@@ -607,33 +613,38 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         constexpr bool KEEPA = !(BM == 256 && BN == 320);
         constexpr int NAL = 2, NAH = NA - 2;                   // A pieces requested in phase L (every low piece is among them) / in phase H
         u32x4 fal[KEEPA ? FH : 1], fbl[FN];                    // lo fragments (fa / fb hold the hi ones); w_hi / w_lo stay for both phases of a stage
+        // one product: C[m = l15][n = 4g + r] (row-major epilogues) or, TRANS, C[m = 4g + r][n = l15] (operands swap roles)
+        auto mm = [&](const u32x4& w_, const u32x4& a_, f32x4& c_) {
+            if constexpr (TRANS) DT<T>::mma(a_, w_, c_);
+            else DT<T>::mma(w_, a_, c_);
+        };
         auto mfma3 = [&](auto I0, int b_) {
             constexpr int i0 = decltype(I0)::value;
             if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < FH; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) DT<T>::mma(fb[j], fa[i], acc[i0 + i][j]);                  // A_hi x W_hi
+                for (int j = 0; j < FN; ++j) mm(fb[j], fa[i], acc[i0 + i][j]);                  // A_hi x W_hi
             if constexpr (KEEPA) {
 #pragma unroll
                 for (int i = 0; i < FH; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) DT<T>::mma(fb[j], fal[i], acc[i0 + i][j]);             // A_lo x W_hi
+                    for (int j = 0; j < FN; ++j) mm(fb[j], fal[i], acc[i0 + i][j]);             // A_lo x W_hi
 #pragma unroll
                 for (int i = 0; i < FH; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) DT<T>::mma(fbl[j], fa[i], acc[i0 + i][j]);             // A_hi x W_lo
+                    for (int j = 0; j < FN; ++j) mm(fbl[j], fa[i], acc[i0 + i][j]);             // A_hi x W_lo
             } else {
 #pragma unroll
                 for (int i = 0; i < FH; ++i) {
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) DT<T>::mma(fbl[j], fa[i], acc[i0 + i][j]);             // A_hi x W_lo (row i), then a_lo[i] over a_hi[i]
+                    for (int j = 0; j < FN; ++j) mm(fbl[j], fa[i], acc[i0 + i][j]);             // A_hi x W_lo (row i), then a_lo[i] over a_hi[i]
                     fa[i] = *reinterpret_cast<const u32x4*>(smem + b_ * BUF + a_rd1 + (i0 + i) * 2048);
                 }
 #pragma unroll
                 for (int i = 0; i < FH; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) DT<T>::mma(fb[j], fa[i], acc[i0 + i][j]);              // A_lo x W_hi
+                    for (int j = 0; j < FN; ++j) mm(fb[j], fa[i], acc[i0 + i][j]);              // A_lo x W_hi
             }
             if (PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
         };

@@ -616,3 +616,42 @@ def test_full_size_n50_schedules_vs_oracle_fixture(gpu, case):
             assert np.abs(img[::4, ::4].astype(int) - g["img"].astype(int)).max() <= 1
         del model
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("case", ["fs_bg_s1", "fs_cmp_s15"])
+def test_full_size_n50_other_hooks_vs_oracle_fixture(gpu, case):
+    """The other two hooks at FULL size on the metric's N = 50 schedules (round 5; G10 covered the edit hook only): background generation at
+    start_step 1 (freefine_batch_infer_bggen_2d.py:149,166-180: 49 + 49 forwards, planted denoiser path) and the cross-image composition with
+    R = 2 references at start_step 15 (Appearance_transfer.ipynb / SURVEY 8d C4: 35 + 35 forwards of 3 / 4 rows, stored reference K / V on) --
+    SD-2.1-base topology, 512^2, against the trajectory OraclePipeline produced in the build container (tests/golden/g10_fullsize_<case>.npz,
+    tools/gen_fullsize_traj.py).  Gate: ABSOLUTE latent L-inf <= 1e-3 at every step of the edited row, fp32 parity mode and split-bf16 mode,
+    through the captured hipGraphs; bf16 printed.  Reference loops: /root/reference/src/demo/model.py:656-812, 301-435."""
+    from golden_cases import fullsize_hook_cases, fullsize_hook_inputs
+    from freefine_amd.config import UNetConfig
+    from freefine_amd.weights import plant_denoiser_path
+    from oracle import sd_unet
+    g = np.load(os.path.join(GOLD, f"g10_fullsize_{case}.npz"))
+    img0, coarse0, img2, oris, tgts = fullsize_hook_inputs()
+    hook, planted, kw = fullsize_hook_cases()[case]
+    ust = sd_unet.init_unet(sd_unet.unet_config("sd21-base"), seed=0).state_dict()
+    if planted > 0:
+        ust = plant_denoiser_path(ust, UNetConfig.preset("sd21-base"), planted)
+    ref = g["traj_edit"]
+    for mode, dtype, x3 in (("fp32", torch.float32, False), ("split-bf16", torch.float32, True), ("bf16", torch.bfloat16, False)):
+        model = make_pipe(gpu, "sd21-base", hook, dtype=dtype, graph=True, ustate=ust, x3=x3)
+        if hook == "bggen":
+            img = model.FreeFine_background_generation(img0, model.dilate_mask(oris[0] // 255, 30), "empty scene", 7.5, 1.0, verbose=True, seed=7,
+                                                       return_intermediates=True, **kw)
+        else:
+            img = model.FreeFine_cross_image_composition([img0, img2], oris, tgts, coarse0, ["a cup", "a dog"], 7.5, 1.0, verbose=True, seed=11,
+                                                         return_intermediates=True, **kw)
+        traj = torch.stack([(t if t.ndim == 3 else t[0]).detach().float().cpu() for t in model.last_intermediates])
+        assert traj.shape[0] == ref.shape[0] == kw["num_step"] - kw["start_step"] + 1
+        d = (traj - torch.from_numpy(ref)).abs().flatten(1).max(1).values
+        print(f"full-size {case} ({hook}), {mode}: ABSOLUTE latent L-inf vs oracle fixture over {traj.shape[0] - 1} guided steps: max {d.max():.2e} "
+              f"(final {d[-1]:.2e}); |latent| max {np.abs(ref).max():.2f}; image max |diff| {np.abs(img[::4, ::4].astype(int) - g['img'].astype(int)).max()}")
+        if mode != "bf16":
+            assert d.max() < TOL, (case, mode)
+            assert np.abs(img[::4, ::4].astype(int) - g["img"].astype(int)).max() <= 1
+        del model
+        torch.cuda.empty_cache()

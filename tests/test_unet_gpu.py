@@ -177,17 +177,19 @@ def test_unet_full_size_768px_latent_96x96(gpu):
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("hook", ["edit", "bggen"])
+@pytest.mark.parametrize("hook", ["edit", "bggen", "compose"])
 def test_unet_full_size_modulated_64x64(gpu, hook):
     """SD-2.1-base topology at the 64x64 latent with the attention-modulation hooks ON (TCA in blocks 10-15 at S = 4096 / 1024 with
     512^2 masks, local cross-attention in all 16 blocks), B = 4 rows [u_e, u_r, c_e, c_r]: the guided forward of BASELINE config 2
-    against the CPU oracle (pinned to the reference's hooks by G1/G2/G5).  fp32 parity mode <= 2e-4 of the output scale; the bf16
+    against the CPU oracle (pinned to the reference's hooks by G1/G2/G5).  hook = compose (round 5): the composition hook's guided forward
+    (/root/reference/src/utils/attention.py:1284-1324, model.py:301-435) with R = 2 references -- rows [edit, ref 1, ref 2, edit] against
+    the R + 1 + P = 6 text rows of forward_sampling_compose (P = 3 prompts: two objects + the empty one).  fp32 parity mode <= 2e-4 of the output scale; the bf16
     fast mode runs the same forward through attn_pp_kernel<true> / xattn_mp_kernel / igemm_pp_kernel and its deviation is printed."""
     from oracle import sd_unet
     torch.set_num_threads(max(8, min(32, torch.get_num_threads())))
     onet = sd_unet.init_unet(sd_unet.unet_config("sd21-base"), seed=0)
     D = onet.cfg.cross_attention_dim
-    x, enc = rng_tensor(31, (4, 4, 64, 64)), rng_tensor(32, (4, 77, D))
+    x, enc = rng_tensor(31, (4, 4, 64, 64)), rng_tensor(32, (4 if hook != "compose" else 4 - 1 + 3, 77, D))
     ref = None
     from freefine_amd.config import UNetConfig
     from freefine_amd.unet import HipUNet
