@@ -52,6 +52,23 @@
 #ifndef PP_ABL
 #define PP_ABL 0      // timing-only ablation builds of tools/native/pp_bench.hip: 1 = no global loads, 2 = no counted waits, 3 = GEGLU without the GELU, 4 = no epilogue stores (results garbage)
 #endif
+#ifndef PP_TAPINNER
+#define PP_TAPINNER 1     // split-bf16 convolutions: K walk chunk-major (taps innermost); 0 = tap-major (A/B builds of tools/native/x3_bench.hip)
+#endif
+#ifdef PP_STAMP
+// tools/native/x3_bench.hip -DPP_STAMP: shader-clock stamps (s_memtime) of one workgroup's waves at the 8 segment boundaries of 4 consecutive stages,
+// collected in LDS (behind the kernel's own 2 BUF + 12 KiB) and copied out at the end -- where a stage's cycles go.  Never defined in the library.
+__device__ unsigned long long pp_stamp_out[8 * 64];
+#define PP_STAMP_AT(k_) do { if (blockIdx.x == 7 && s >= 24 && s < 28) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    if (lane == 0) *reinterpret_cast<unsigned long long*>(smem + CV + 12288 + (wave * 64 + (s - 24) * 16 + (k_)) * 8) = t_; } } while (0)
+#else
+#define PP_STAMP_AT(k_) do {} while (0)
+#endif
+#ifdef PP_NBE
+#define X3_NBE(FN_, NA_) (PP_NBE)
+#else
+#define X3_NBE(FN_, NA_) ((FN_) + 2 - ((FN_) + (NA_) + 1) / 2)      // early W pieces per wave and stage of the split-bf16 core (see its loop)
+#endif
 template <int N>
 __device__ __forceinline__ void pp_wait_vmcnt() {
     if (PP_ABL != 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -179,18 +196,45 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     // X3: a pixel's Cin channels are Cin / 32 blocks [hi(32) | lo(32)] of 128 bytes = Cin / 32 K tiles per tap (PIX = 4 Cin bytes per pixel)
     const int cpt = AMODE == AMODE_DENSE ? 1 : (X3 ? p.Cin / 32 : p.Cin / 64);      // K tiles per tap
     const int cpt_rcp = (65536 + cpt - 1) / cpt;
+    // Split-bf16 convolutions walk K CHUNK-major (round 5): the taps of one 32-channel block back to back, then the next block.  With three MFMAs per
+    // product the stage's load sections, not its MFMA sections, set the pace (in-kernel stamps, profiles/r5_x3_stamps.txt: 990 + 780 cycles of
+    // load sections beside 2 x 720 of MFMA on the 192 x 320 tile), and what they wait for is the issue of LDS-DMA pieces whose lines come from
+    // beyond L2: tap-major, the nine taps re-read a tile's pixels 10 stages apart and the per-XCD footprint between two taps exceeds the 4 MiB L2
+    // (40 % of the launch's requests miss it: TCC_HIT 1.5e7 / MISS 1.0e7, FETCH_SIZE = 9 x the activations); chunk-major, eight of the nine taps
+    // find their lines where the previous stage left them.  (Round 2 measured the same walk 5-13 % SLOWER on the bf16 kernel: there the MFMA section
+    // was a third as long and the loader's per-stage tap arithmetic was the pole.)  W rows keep their tap-major packing -- only the walk changes:
+    // stage kt reads W columns (tap * cpt + chunk) * 64.
+    constexpr bool TAPIN = X3 && AMODE != AMODE_DENSE && PP_TAPINNER;
+    const int ntap = p.conv == 2 ? 4 : 9;
+    auto kt_split = [&](int kt, int& tap, int& c) {
+        if (TAPIN) {
+            c = p.conv == 2 ? (kt >> 2) : ((kt * 7282) >> 16);      // kt / 9: exact below 32768
+            tap = kt - c * ntap;
+        } else {
+            tap = (kt * cpt_rcp) >> 16;
+            c = kt - tap * cpt;
+        }
+    };
     int ka = 0, tap_ky = 0, tap_kx = 0, tap_off = 0;  // of K tile l_kt; set by k_position()
     auto k_position = [&]() {
         const int kt = l_k0 + l_kt;
         if (AMODE == AMODE_DENSE) {
             ka = kt * 128;
         } else {
-            const int tap = (kt * cpt_rcp) >> 16;
-            ka = (kt - tap * cpt) * 128;
+            int tap, c;
+            kt_split(kt, tap, c);
+            ka = c * 128;
             tap_ky = p.conv == 2 ? (tap >> 1) : ((tap * 21846) >> 16);       // taps per window row: 2 (conv == 2) or 3
             tap_kx = tap - (p.conv == 2 ? 2 : 3) * tap_ky;
             tap_off = (tap_ky * p.Win + tap_kx) * PIX;
         }
+    };
+    auto w_position = [&]() {                         // byte offset of the loader's K tile inside a W row
+        const int kt = l_k0 + l_kt;
+        if (!TAPIN) return kt * 128;
+        int tap, c;
+        kt_split(kt, tap, c);
+        return (tap * cpt + c) * 128;
     };
     auto prep = [&](int wtile) {                      // loader state at the first K tile of walk step `wtile`
         const int tile = wtile / nsl;
@@ -231,8 +275,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         if (PP_ABL != 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)(smem + buf * BUF + apiece[i] * 1024), 16, voff, ka, 0, 0);
     };
     auto issue_b = [&](int i, int buf) {
-        if (PP_ABL != 1)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(smem + buf * BUF + ABYTES + (wave + 8 * i) * 1024), 16, b_voff, (l_k0 + l_kt) * 128 + i * b_step, 0, 0);
+        const int so = w_position() + i * b_step;     // (a lambda call inside the builtin's argument list made hipcc 7.2 drop the whole kernel without a diagnostic)
+        if (PP_ABL != 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(smem + buf * BUF + ABYTES + (wave + 8 * i) * 1024), 16, b_voff, so, 0, 0);
     };
     // column vectors of output tile `tile` for THIS wave: bias[n0 + wc*WN ..) and the row bias of the (at most two: the launcher
     // requires rows_per_batch >= HM) images the wave's HM rows belong to, 2 x 64 floats each (lanes past WN fetch nothing: zeros),
@@ -598,6 +642,13 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     for (int i = 0; i < NA; ++i) issue_a(i, 0);
     advance();
     pp_wait_vmcnt<0>();
+    if constexpr (X3) {                               // split-bf16 core: the early W pieces of stage 1 (see the loop), in flight across the first barrier
+        constexpr int NBE0 = X3_NBE(BN / 64, BM / 64);
+        if (S > 1) {
+#pragma unroll
+            for (int i = 0; i < NBE0; ++i) issue_b(i, 1);
+        }
+    }
     init_rows(first, I0_t{});
     init_rows(first, I4_t{});
     pp_barrier();
@@ -612,6 +663,14 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
         // the MFMA section; W rows are re-staged in the very next phase L, so W fragments are only ever read in phase L's load section).
         constexpr bool KEEPA = !(BM == 256 && BN == 320);
         constexpr int NAL = 2, NAH = NA - 2;                   // A pieces requested in phase L (every low piece is among them) / in phase H
+        // W pieces of stage s + 2 requested EARLY, in phase H of stage s (right behind the loader's step to s + 2, into the CURRENT buffer, whose W
+        // rows were last read in this stage's phase L: retired by the lgkmcnt(0) in front of that phase's barrier), the rest in phase L of stage
+        // s + 1: the LDS-DMA issue, the long pole of a load section (100-185 cycles per piece beside the partner's MFMAs), is then spread evenly
+        // over the two phases (192 x 320: 4 + 4 pieces instead of 7 + 1) instead of making phase L's load section twice its MFMA section
+        constexpr int NBE = X3_NBE(FN, NA);
+        constexpr int NBL = FN - NBE;
+        (void)NBL;
+        static_assert(NBE >= 0 && NBE <= FN, "early W pieces");
         u32x4 fal[KEEPA ? FH : 1], fbl[FN];                    // lo fragments (fa / fb hold the hi ones); w_hi / w_lo stay for both phases of a stage
         // one product: C[m = l15][n = 4g + r] (row-major epilogues) or, TRANS, C[m = 4g + r][n = l15] (operands swap roles)
         auto mm = [&](const u32x4& w_, const u32x4& a_, f32x4& c_) {
@@ -667,47 +726,65 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
 
             // ---- phase L: low rows ----
             __builtin_amdgcn_sched_barrier(0);
+            PP_STAMP_AT(0);
             if (p_tile >= 0) {
                 // first stage of a new output tile (never the last stage of the stream: nk >= 2).  The previous tile's high rows, final since
                 // the phase-H MFMAs, leave now; its low rows left in that phase H.  VM queue, oldest first:
                 //   A-high of this stage | this tile's column vectors | low stores | high stores | W x FN | A-low x NAL     (see the bf16 loop below)
                 store_rows(p_tile, I4_t{});
 #pragma unroll
-                for (int i = 0; i < FN; ++i) issue_b(i, nb);
+                for (int i = NBE; i < FN; ++i) issue_b(i, nb);
                 k_position();
                 issue_a(0, nb);
                 issue_a(1, nb);
-                pp_wait_vmcnt<FN + NAL + 2 * NST>();  // through A-high and the column vectors
+                pp_wait_vmcnt<FN + NAL + 2 * NST>();  // through A-high and the column vectors (younger: early W, the stores, A-low, late W)
                 init_rows(c_tile, I0_t{});
                 __builtin_amdgcn_sched_barrier(0);    // the fragment reads last: their registers are free for the epilogue's temporaries
                 read_low_set(buf);
             } else {
                 read_low_set(buf);
+                PP_STAMP_AT(8);
                 if (more) {
 #pragma unroll
-                    for (int i = 0; i < FN; ++i) issue_b(i, nb);
+                    for (int i = NBE; i < FN; ++i) issue_b(i, nb);
                     k_position();
                     issue_a(0, nb);
                     issue_a(1, nb);
-                    pp_wait_vmcnt<FN + NAL>();        // A-high of THIS stage (requested in phase H of the previous one) has landed
+                    PP_STAMP_AT(9);
+                    pp_wait_vmcnt<FN + NAL>();        // A-high of THIS stage (requested in phase H of the previous one, in front of the early W pieces) has landed
                 } else {
                     pp_wait_vmcnt<0>();
                 }
+                PP_STAMP_AT(10);
             }
+            if (NBE > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this stage's W rows are re-staged from the next phase on: their reads retire HERE
             __builtin_amdgcn_sched_barrier(0);
+            PP_STAMP_AT(1);
             pp_barrier();
+            PP_STAMP_AT(2);
             mfma3(I0_t{}, buf);
             __builtin_amdgcn_sched_barrier(0);
+            PP_STAMP_AT(3);
             pp_barrier();
+            PP_STAMP_AT(4);
 
             // ---- phase H: high rows ----  (tile-boundary work BEFORE the fragment reads: the A set's registers are free for its temporaries)
             if (more) {
 #pragma unroll
                 for (int i = 2; i < NA; ++i) issue_a(i, nb);
-                advance();
-                // W and A-low of the next stage have landed (this phase's A-high pieces, and the next output tile's 6 column-vector loads, may fly)
-                if (switched) pp_wait_vmcnt<NAH + (SPLIT ? 0 : 6)>();
-                else pp_wait_vmcnt<NAH>();
+                advance();                            // the loader now stands on stage s + 2
+                const bool more2 = s + 2 < S;
+                if (more2) {
+#pragma unroll
+                    for (int i = 0; i < NBE; ++i) issue_b(i, buf);
+                }
+                // W and A-low of the next stage have landed (this phase's A-high and early W pieces, and the next output tile's 6 column-vector loads, may fly)
+                if (more2) {
+                    if (switched) pp_wait_vmcnt<NAH + NBE + (SPLIT ? 0 : 6)>();
+                    else pp_wait_vmcnt<NAH + NBE>();
+                } else {
+                    pp_wait_vmcnt<NAH>();             // (the loader never switches tiles behind the last stage)
+                }
             }
             if (p_tile >= 0) {                        // the high rows of the new tile start
                 init_rows(c_tile, I4_t{});
@@ -717,9 +794,12 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
             __builtin_amdgcn_sched_barrier(0);
             read_a_set(buf, FH);
             __builtin_amdgcn_sched_barrier(0);
+            PP_STAMP_AT(5);
             pp_barrier();
+            PP_STAMP_AT(6);
             mfma3(I4_t{}, buf);
             __builtin_amdgcn_sched_barrier(0);
+            PP_STAMP_AT(7);
             pp_barrier();
 
             buf = nb;
@@ -839,4 +919,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     }
     if (p_tile >= 0) store_rows(p_tile, I4_t{});
     if (wr == 0) pp_barrier();                        // balance the lagging group's extra barrier
+#ifdef PP_STAMP
+    if (blockIdx.x == 7) pp_stamp_out[tid] = *reinterpret_cast<const unsigned long long*>(smem + CV + 12288 + tid * 8);
+#endif
 }

@@ -71,7 +71,11 @@ int main(int argc, char** argv) {
     if (use_geglu) d.flags |= FFN_IG_GEGLU | FFN_IG_OUT_PAIR;
     const int nt = ((d.M + bm - 1) / bm) * (d.N / bn);
     const int grid = nt < 256 ? nt : 256;
+#ifdef PP_STAMP
+    const int lds = 2 * (bm + bn) * 128 + 12288 + 4096;
+#else
     const int lds = 2 * (bm + bn) * 128 + 12288;
+#endif
     auto run = [&]() {
 #define PPL(BM_, BN_, AM_, R_, G_) launch_pp(igemm_pp_kernel<BM_, BN_, AM_, R_, G_, false, false, true, false>, grid, lds, d, 1)
 #define PPB(BM_)                                                                                                                     \
@@ -99,6 +103,24 @@ int main(int argc, char** argv) {
         t = t * 1e3f / reps;
         if (t < best) best = t;
     }
+#ifdef PP_STAMP
+    {   // one launch's stamps of workgroup 7, stages 24-27: per wave the segment boundaries (0-7) and three points inside phase L's load section (8-10)
+        run(); CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> st(512);
+        CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(pp_stamp_out), 512 * 8));
+        printf("segments (cycles), mean over stages 24-27:   load L [reads issued | DMA issued | vmcnt wait | lgkm wait]  barrier   mfma L   barrier   load H   barrier   mfma H   barrier\n");
+        for (int w = 0; w < 8; ++w) {
+            double seg[8] = {0}, sub[4] = {0};
+            for (int g = 0; g < 4; ++g) {
+                const unsigned long long* t = &st[w * 64 + g * 16];
+                for (int k = 0; k < 7; ++k) seg[k] += (double)(t[k + 1] - t[k]) / 4;
+                if (g < 3) seg[7] += (double)(t[16] - t[7]) / 3;
+                sub[0] += (double)(t[8] - t[0]) / 4; sub[1] += (double)(t[9] - t[8]) / 4; sub[2] += (double)(t[10] - t[9]) / 4; sub[3] += (double)(t[1] - t[10]) / 4;
+            }
+            printf("wave %d: %8.0f [%5.0f %5.0f %5.0f %5.0f] %6.0f %8.0f %6.0f %8.0f %6.0f %8.0f %6.0f\n", w, seg[0], sub[0], sub[1], sub[2], sub[3], seg[1], seg[2], seg[3], seg[4], seg[5], seg[6], seg[7]);
+        }
+    }
+#endif
     printf("PP_ABL=%d %s M=%d N=%d K=%d opt=%s tile %dx%d: %.1f us  %.0f TFLOP/s (%.2f of 833)\n", PP_ABL, conv ? "conv" : "dense", d.M, d.N, Kr, opt, bm, bn, best,
            flops / best * 1e-6, flops / best * 1e-6 / 833.3);
     return 0;
