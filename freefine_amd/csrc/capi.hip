@@ -81,6 +81,13 @@ extern "C" int ffn_device_info(int device, char* name, int name_len) {
     return prop.multiProcessorCount;
 }
 
+extern "C" int ffn_graph_launch(void* stream, void* graph_exec) {
+    REQUIRE(graph_exec, "graph_launch: null graph");
+    hipError_t e = hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(graph_exec), reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(FFN_EHIP, "hipGraphLaunch: %s", hipGetErrorString(e));
+    return FFN_OK;
+}
+
 // ---- igemm -------------------------------------------------------------------------------------------------------
 static void igemm_plan_for(int dtype, const ffn_igemm_desc& d, int* bm, int* bn, int* splitk);
 static int igemm_stages_env() {

@@ -13,13 +13,17 @@ MI355X-first layout decisions
   * per-step scalars (timestep, context_guidance) live in device memory, so a whole forward can be captured in a hipGraph
     and replayed (capture=True) -- ~700 launches become one graph launch.
 """
+import ctypes as CT
 import os
 import weakref
 
 import torch
 
+from . import _lib as L
 from . import ops
 from .config import UNetConfig
+
+_GRAPH_RAW = os.environ.get("FFN_GRAPH_RAW", "1") != "0"
 
 
 class _Res:
@@ -292,10 +296,24 @@ class HipUNet:
             assert len(g["ref_in"]) == len(ru["state"])
             for dst, src in zip(g["ref_in"], ru["state"]):
                 dst.copy_(src)
-        g["graph"].replay()
+        self._launch(g)
         if ru is not None and ru["mode"] == "record":
             self.last_boundary, self.last_kv = g["boundary"], g["kv"]
         return self._expand(g["out"].clone())
+
+    @staticmethod
+    def _launch(g):
+        """replay a captured forward.  Through the C ABI (ffn_graph_launch = hipGraphLaunch on the current stream): a ctypes call releases the GIL,
+        torch's CUDAGraph.replay() holds it -- and a launch of the ~380-node graph keeps the host thread for milliseconds on ROCm 7.2 (measured:
+        5.2 ms per replay, profiles/r5_host_profile_batch1.txt), which serialised the host threads of the one-image-per-call layout.  The graphs
+        hold no torch RNG state, so the raw launch is the whole of replay().  FFN_GRAPH_RAW=0 keeps torch's replay()."""
+        if _GRAPH_RAW:
+            ex = g.get("exec")
+            if ex is None:
+                ex = g["exec"] = int(g["graph"].raw_cuda_graph_exec())
+            L.check(L.load().ffn_graph_launch(CT.c_void_p(torch.cuda.current_stream().cuda_stream), CT.c_void_p(ex)), "ffn_graph_launch")
+        else:
+            g["graph"].replay()
 
     def _prepare_reuse(self, reuse, B, enc):
         if reuse is None:

@@ -36,6 +36,12 @@ int ffn_version(void);
 const char* ffn_last_error(void);
 /* fills name (<=64 bytes) with the gcnArchName of `device`, returns CU count or negative error. */
 int ffn_device_info(int device, char* name, int name_len);
+/* hipGraphLaunch(graph_exec, stream) through this library's HIP runtime.  Why it is in the ABI: a foreign-function call releases the host
+ * language's interpreter lock, torch.cuda.CUDAGraph.replay() does not -- and on ROCm 7.2 a launch of a ~380-node UNet-forward graph holds the
+ * calling thread for milliseconds, so the one-image-per-call layout (several host threads, one HIP stream each: the reference's
+ * src/demo/model.py:577-617 loop run as it stands) serialised on that lock.  graph_exec = the hipGraphExec_t of a captured forward
+ * (torch: CUDAGraph.raw_cuda_graph_exec()). */
+int ffn_graph_launch(void* stream, void* graph_exec);
 
 /* ---- implicit GEMM: Linear / 1x1 conv (dense A) and 3x3 conv (im2col gather) ------------------------------
  * out[m,n] = epi( alpha * sum_k A(m,k) W[n,k] ), W is [N][Kpad]: K contiguous, Kpad = row stride of W (>= K, multiple of
