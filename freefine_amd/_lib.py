@@ -45,7 +45,7 @@ class AttnDesc(C.Structure):
         ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("out", C.c_void_p), ("w_dev", C.c_void_p),
         ("Bo", C.c_int), ("S", C.c_int), ("Sk", C.c_int), ("heads", C.c_int), ("D", C.c_int),
         ("ldq", C.c_int), ("ldk", C.c_int), ("ldvt", C.c_int), ("ldo", C.c_int),
-        ("scale", C.c_float), ("npass", C.c_int), ("out_pair", C.c_int), ("reserved", C.c_int),
+        ("scale", C.c_float), ("npass", C.c_int), ("out_pair", C.c_int), ("kv_pair", C.c_int),
         ("e", AttnEntry * (ATT_MAXP * ATT_MAXB)),
     ]
 
@@ -95,6 +95,7 @@ SYMBOLS = {
     "ffn_igemm_force_config": (_i, [_i]),
     "ffn_igemm_variant": (_i, [C.POINTER(IgemmDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ffn_igemm_kernel_name": (_i, [_i, C.POINTER(IgemmDesc), C.c_char_p, _i]),
+    "ffn_attn_presplit": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "ffn_attn_variant": (_i, [_i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ffn_gn_nchunk": (_i, [_i]),
     "ffn_gn_fused": (_i, [_i, _i, _i, _i]),

@@ -26,12 +26,24 @@
 #include "attention_pp.h"
 #include "attention_x3.h"
 
-template <bool MASKS>
+#ifndef X3P_ABL
+#define X3P_ABL 0     // timing-only ablation builds of tools/native/x3p_bench.hip: 1 = no in-loop staging (tiles 0 / 1 stay in the rings: results garbage)
+#endif
+// PAIRKV (round 5): K and V^T arrive PRE-SPLIT -- ffn_attn_presplit writes them once per attention call as bf16 images in exactly the tiles this
+// kernel stages: K as [row][key][head][hi(64 d) | lo(64 d)], V^T as [row][head * 64 + d][key tile][hi(64 keys) | lo(64 keys)], every 128-byte
+// line wholly hi or lo -- and the tiles go global -> LDS by LDS-DMA (four 1 KiB pieces per wave and tile: K_hi, K_lo, V^T_hi, V^T_lo; the K-row
+// permutation and the XOR swizzle are applied to the per-lane SOURCE offset; the key-mask bytes of a tile ride along as a fifth, 4-byte, piece),
+// requested at the START of M segment t for tile t + 2 and waited for (vmcnt(0)) at its end.  The in-loop staging of the fp32 form -- four
+// global_load_dwordx4 to registers, two 24-instruction splits, four ds_write_b128 per wave and tile, repeated by all 16 query-block workgroups of a
+// (row, head) -- cost 16-25 % of the launch (timing ablation, profiles/r5_x3p_staging_ablation.txt); the one-off split pass costs 2-5 %.
+template <bool MASKS, bool PAIRKV = false>
 __global__ __launch_bounds__(512) void attn_x3p_kernel(const AttnParams p) {
     constexpr int D = 64, KT = 64, QF = 2, NT = 4, FD = 4, DSL = 2, NC = 2;     // NC = 32-key chunks per tile (PV k-steps)
     constexpr int TILE = KT * 128;                              // one bf16 image: 64 rows x 128 B
     constexpr int SLOT = 2 * TILE;                              // hi | lo
     constexpr int OFF_V = 2 * SLOT, OFF_TOT = OFF_V + 3 * SLOT; // K slots 0, 1 | V^T slots 0, 1, 2 | multi-pass sums (144 KB in all)
+    constexpr int OFF_M = OFF_TOT + 8 * (FD * QF * 64) * 16;    // PAIRKV: key-mask bytes of the two K tiles in flight, 256 B each
+    constexpr int OOB = (int)0x80000000;
     constexpr float FAST_THR = 6.0f;
     constexpr float NEG = -1e30f;
 
@@ -171,10 +183,36 @@ __global__ __launch_bounds__(512) void attn_x3p_kernel(const AttnParams p) {
         uint32_t mbytes = 0;
         auto fetch_mask = [&](int t) {
             if (MASKS && pass_masked && t < ntiles) {
-                const uint8_t* mb = en.kmask + t * KT + 8 * (l15 >> 2) + (l15 & 3);
-                mbytes = (uint32_t)mb[0] | ((uint32_t)mb[4] << 8) | ((uint32_t)mb[32] << 16) | ((uint32_t)mb[36] << 24);     // tt = 0 .. 3: key 32 (tt >> 1) + 4 (tt & 1) + ...
+                if constexpr (PAIRKV) {                         // the tile's 64 mask bytes came by LDS-DMA beside its K images (slot t & 1)
+                    const uint8_t* mb = reinterpret_cast<const uint8_t*>(smem + OFF_M + (t & 1) * 256) + 8 * (l15 >> 2) + (l15 & 3);
+                    mbytes = (uint32_t)mb[0] | ((uint32_t)mb[4] << 8) | ((uint32_t)mb[32] << 16) | ((uint32_t)mb[36] << 24);
+                } else {
+                    const uint8_t* mb = en.kmask + t * KT + 8 * (l15 >> 2) + (l15 & 3);
+                    mbytes = (uint32_t)mb[0] | ((uint32_t)mb[4] << 8) | ((uint32_t)mb[32] << 16) | ((uint32_t)mb[36] << 24);     // tt = 0 .. 3: key 32 (tt >> 1) + 4 (tt & 1) + ...
+                }
             }
         };
+        // PAIRKV: this wave's four pieces of a tile (LDS rows 8 wave .. 8 wave + 7 of each image).  LDS row r, 16-byte position c' holds chunk
+        // c' ^ (r & 7) of key (K) / of d row (V^T) r; K rows are the key permutation row 16 tq + 4 gq + rr <-> key 32 (tq >> 1) + 8 gq + 4 (tq & 1) + rr
+        const int dr = 8 * wave + (lane >> 3), dc = ((lane & 7) ^ (dr & 7)) * 16;
+        const int dkey = 32 * (dr >> 5) + 8 * ((dr >> 2) & 3) + 4 * ((dr >> 4) & 1) + (dr & 3);
+        const int k_voff = dkey * p.heads * 256 + dc, v_voff = dr * (p.Sk / KT) * 256 + dc;
+        const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.k), 0, PAIRKV ? 0x7ffff000 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.vt), 0, PAIRKV ? 0x7ffff000 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(en.kmask), 0, (PAIRKV && MASKS && pass_masked) ? p.Sk : 0, 0x00020000);
+        auto dma_tile = [&](int t, int vs) {                    // tile t -> K slot t & 1, V^T slot vs (t >= ntiles: nothing)
+            if (!PAIRKV || t >= ntiles) return;
+            const int ks = ((en.kv_row * p.Sk + t * KT) * p.heads + head) * 256;
+            const int vsoff = ((en.kv_row * p.heads * D + head * D) * (p.Sk / KT) + t) * 256;
+            char* Kd = smem + (t & 1) * SLOT + wave * 1024;
+            char* Vd = smem + OFF_V + vs * SLOT + wave * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (att_lptr_t)Kd, 16, k_voff, ks, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (att_lptr_t)(Kd + TILE), 16, k_voff, ks + 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (att_lptr_t)Vd, 16, v_voff, vsoff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (att_lptr_t)(Vd + TILE), 16, v_voff, vsoff + 128, 0, 0);
+            if (MASKS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, (att_lptr_t)(smem + OFF_M + (t & 1) * 256), 4, lane < 16 ? lane * 4 : OOB, t * KT, 0, 0);
+        };
+        auto dma_done = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
         // Fragment reads are software-pipelined by hand in groups of four ds_read_b128 (hi and lo images of two fragments: 16 registers)
         // that feed 12 MFMAs; two register buffers alternate, every group is requested while the previous one's MFMAs run.
@@ -287,14 +325,21 @@ __global__ __launch_bounds__(512) void attn_x3p_kernel(const AttnParams p) {
         auto lds_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
 
         // ---- prologue: tiles 0 and 1 staged; S(0) computed ------------------------------------------------------------------------
-        fetch_k(0); fetch_v(0);
-        fetch_mask(0);
-        stage_k(0); stage_v(0);
-        fetch_k(1); fetch_v(1);
-        stage_k(1); stage_v(1);
-        lds_done();
+        if constexpr (PAIRKV) {
+            dma_tile(0, 0);
+            dma_tile(1, 1);
+            dma_done();
+        } else {
+            fetch_k(0); fetch_v(0);
+            fetch_mask(0);
+            stage_k(0); stage_v(0);
+            fetch_k(1); fetch_v(1);
+            stage_k(1); stage_v(1);
+            lds_done();
+        }
         attpp_barrier();
         attpp_barrier();                                        // both groups' pieces of tiles 0 / 1 are in LDS
+        if constexpr (PAIRKV) fetch_mask(0);
         X3P_SB();
         rd_k(0, 0, 0, fa); rd_k(0, 0, 1, fb);
         qk_start();
@@ -334,8 +379,12 @@ __global__ __launch_bounds__(512) void attn_x3p_kernel(const AttnParams p) {
             // ---- M segment: 8 groups of 12 (+ 4) MFMAs, the next group's fragments requested behind each ----
             __builtin_amdgcn_s_setprio(0);
             const bool more = t + 1 < ntiles;
-            fetch_k(t + 2);
-            fetch_v(t + 2);
+            if constexpr (PAIRKV) {
+                if (X3P_ABL != 1) dma_tile(t + 2, vwr);
+            } else if (X3P_ABL != 1) {
+                fetch_k(t + 2);
+                fetch_v(t + 2);
+            }
             rd_v(vslot, 0, 1, fb); X3P_SB();
             pv_group(I0{}, I0{}, fa); X3P_SB(); rd_v(vslot, 1, 0, fa); X3P_SB();
             pv_group(I0{}, I1{}, fb); X3P_SB(); rd_v(vslot, 1, 1, fb); X3P_SB();
@@ -352,11 +401,16 @@ __global__ __launch_bounds__(512) void attn_x3p_kernel(const AttnParams p) {
                 qk_group(I1{}, I1{}, fb);
             }
             X3P_SB();
-            if (t + 2 < ntiles) {
-                stage_k(t + 2);
-                stage_v(vwr);
+            if constexpr (PAIRKV) {
+                dma_done();                                     // this wave's pieces of tile t + 2 have landed (they had the whole segment)
+                fetch_mask(t + 2);                              // (every wave brought the tile's mask bytes itself: no barrier between its DMA and this read)
+            } else {
+                if (X3P_ABL != 1 && t + 2 < ntiles) {
+                    stage_k(t + 2);
+                    stage_v(vwr);
+                }
+                fetch_mask(t + 2);
             }
-            fetch_mask(t + 2);
             lds_done();
             __builtin_amdgcn_s_setprio(1);
             X3P_SB();
@@ -390,4 +444,37 @@ __global__ __launch_bounds__(512) void attn_x3p_kernel(const AttnParams p) {
         }
     }
     if (grp == 0) attpp_barrier();                              // balance the lagging group's extra barrier
+}
+
+// ---- ffn_attn_presplit: fp32 K / V^T -> the pre-split bf16 images attn_x3p_kernel<., PAIRKV = true> stages by LDS-DMA ------------------------
+// K  [R][Sk][ldk] (heads * 64 columns)   -> bf16 [R][Sk][heads][hi(64) | lo(64)]
+// V^T [R][heads * 64][ldvt] (Sk % 64 = 0) -> bf16 [R][heads * 64][Sk / 64][hi(64 keys) | lo(64 keys)]
+// one thread = 8 values (32 B in, 2 x 16 B out); HBM-bound, once per attention call (the 16 query-block workgroups of a (row, head) used to repeat it)
+__global__ __launch_bounds__(256) void attn_presplit_k_kernel(const float* __restrict__ k, bf16* __restrict__ out, long n, int heads, int ldk) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c8 = (int)(i & 7);
+        const long rh = i >> 3;
+        const int h = (int)(rh % heads);
+        const long rs = rh / heads;
+        const float* src = k + rs * ldk + h * 64 + c8 * 8;
+        u32x4 hi, lo;
+        x3_split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), hi, lo);
+        bf16* dst = out + rh * 128 + c8 * 8;
+        *reinterpret_cast<u32x4*>(dst) = hi;
+        *reinterpret_cast<u32x4*>(dst + 64) = lo;
+    }
+}
+__global__ __launch_bounds__(256) void attn_presplit_vt_kernel(const float* __restrict__ vt, bf16* __restrict__ out, long n, int ntile, int ldvt) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c8 = (int)(i & 7);
+        const long rt = i >> 3;
+        const int t = (int)(rt % ntile);
+        const long rc = rt / ntile;
+        const float* src = vt + rc * ldvt + t * 64 + c8 * 8;
+        u32x4 hi, lo;
+        x3_split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), hi, lo);
+        bf16* dst = out + rt * 128 + c8 * 8;
+        *reinterpret_cast<u32x4*>(dst) = hi;
+        *reinterpret_cast<u32x4*>(dst + 64) = lo;
+    }
 }

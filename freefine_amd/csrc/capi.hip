@@ -1079,6 +1079,16 @@ static bool attn_has_masks(const ffn_attn_desc& d) {
         }
     return false;
 }
+extern "C" int ffn_attn_presplit(void* stream, const float* k, const float* vt, void* k_pair, void* vt_pair, int rows, int Sk, int heads, int ldk, int ldvt) {
+    REQUIRE(k && vt && k_pair && vt_pair && aligned16(k) && aligned16(vt) && aligned16(k_pair) && aligned16(vt_pair), "attn_presplit: null / unaligned pointer");
+    REQUIRE(rows > 0 && heads > 0 && Sk > 0 && Sk % 64 == 0 && ldk >= heads * 64 && ldk % 4 == 0 && ldvt >= Sk && ldvt % 4 == 0,
+            "attn_presplit: rows=%d Sk=%d heads=%d ldk=%d ldvt=%d (head dim 64, Sk %% 64 == 0)", rows, Sk, heads, ldk, ldvt);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long nk = (long)rows * Sk * heads * 8, nv = (long)rows * heads * 64 * (Sk / 64) * 8;
+    LAUNCH(attn_presplit_k_kernel, dim3(grid_for(nk)), dim3(256), 0, s, k, (bf16*)k_pair, nk, heads, ldk);
+    LAUNCH(attn_presplit_vt_kernel, dim3(grid_for(nv)), dim3(256), 0, s, vt, (bf16*)vt_pair, nv, Sk / 64, ldvt);
+    return check_launch("attn_presplit");
+}
 extern "C" int ffn_attn_kernel_name(int dtype, const ffn_attn_desc* d, char* buf, int len) {
     REQUIRE(d && buf && len > 0, "attn_kernel_name: null argument");
     int dp = 0, qf = 0;
@@ -1091,7 +1101,8 @@ extern "C" int ffn_attn_kernel_name(int dtype, const ffn_attn_desc* d, char* buf
         }
         bool masks, pp;
         attn_bf16_choice(*d, &masks, &pp);
-        snprintf(buf, len, "void %s<%s>(ffn_attn_desc)", pp ? "attn_x3p_kernel" : "attn_x3_kernel", attn_has_masks(*d) ? "true" : "false");
+        if (pp) snprintf(buf, len, "void attn_x3p_kernel<%s, %s>(ffn_attn_desc)", attn_has_masks(*d) ? "true" : "false", d->kv_pair ? "true" : "false");
+        else snprintf(buf, len, "void attn_x3_kernel<%s>(ffn_attn_desc)", attn_has_masks(*d) ? "true" : "false");
         return FFN_OK;
     }
     if (dtype == FFN_BF16X3) dtype = FFN_F32;
@@ -1124,6 +1135,15 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
     REQUIRE(d->ldq % epc == 0 && d->ldk % epc == 0 && d->ldvt % epc == 0 && d->ldo % 4 == 0, "attn: leading dims must be chunk aligned");
     REQUIRE(d->ldvt >= d->Sk, "attn: ldvt=%d < Sk=%d", d->ldvt, d->Sk);
     if (d->out_pair) REQUIRE(dtype == FFN_BF16X3 && d->D <= 64 && d->ldo % 16 == 0 && d->ldo / 2 >= d->heads * d->D, "attn: pair output needs FFN_BF16X3, D <= 64, ldo %% 16 == 0");
+    if (d->kv_pair) {
+        bool m_, pp_;
+        attn_bf16_choice(*d, &m_, &pp_);
+        REQUIRE(dtype == FFN_BF16X3 && pp_ && !xattn_nkf(*d, nullptr, 4), "attn: kv_pair is for launches that run attn_x3p_kernel (FFN_BF16X3, D = 64, Sk %% 64 == 0, S >= 128, no uniform-softmax entry)");
+        long maxkv = 0;
+        for (int pi = 0; pi < d->npass; ++pi)
+            for (int b = 0; b < d->Bo; ++b) maxkv = d->e[pi * FFN_ATT_MAXB + b].kv_row > maxkv ? d->e[pi * FFN_ATT_MAXB + b].kv_row : maxkv;
+        REQUIRE((maxkv + 1) * d->Sk * d->heads * 256 < (1l << 31) - 65536, "attn: pre-split K / V^T images beyond 2 GiB (32-bit byte offsets)");
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int D = d->D;
     if (dtype == FFN_BF16X3 && D <= 64) {      // split-bf16 arithmetic on fp32 operands (attention_x3.h); other head sizes: the exact fp32 kernel
@@ -1137,6 +1157,17 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
         attn_bf16_choice(*d, &masks_pp, &pp);      // the ping-pong schedule has the same preconditions as attn_pp_kernel's (d = 64, Sk % 64 == 0, S >= 128, ...)
         if (pp) {
             constexpr int lds = 5 * (2 * 8192) + 8 * 4 * 2 * 64 * 16;      // K ring of 2 + V^T ring of 3 [hi | lo] images, multi-pass sums
+            if (d->kv_pair) {                       // pre-split K / V^T images by LDS-DMA (+ 512 B of key-mask bytes)
+                constexpr int ldsp = lds + 512;
+                if (attn_has_masks(*d)) {
+                    if ((rc = set_lds(attn_x3p_kernel<true, true>, ldsp))) return rc;
+                    LAUNCH((attn_x3p_kernel<true, true>), grid, dim3(512), ldsp, s, *d);
+                } else {
+                    if ((rc = set_lds(attn_x3p_kernel<false, true>, ldsp))) return rc;
+                    LAUNCH((attn_x3p_kernel<false, true>), grid, dim3(512), ldsp, s, *d);
+                }
+                return check_launch("attn(split-bf16, ping-pong, pre-split K/V)");
+            }
             if (attn_has_masks(*d)) {
                 if ((rc = set_lds(attn_x3p_kernel<true>, lds))) return rc;
                 LAUNCH(attn_x3p_kernel<true>, grid, dim3(512), lds, s, *d);

@@ -86,9 +86,12 @@ def _igemm_name(lib, dcode, d):
 # ---------------------------------------------------------------------------------------------------------------
 # weight packing (host side, once at load time)
 # ---------------------------------------------------------------------------------------------------------------
+_ATTN_PRESPLIT = os.environ.get("FFN_ATTN_PRESPLIT", "1") != "0"      # split-bf16 self attention: pre-split K / V^T once per call (0: split inside the kernel's key loop)
+
+
 def _mark_x3(t, order=1):
     t._ffn_x3 = order         # linear() / conv3x3() recognise a split-bf16 weight by this tag and run the FFN_BF16X3 path
-    return t                  # (1 = plane order [hi | lo | hi] over the whole K / tap, 2 = chunk order: that triple per 64-element chunk)
+    return t                  # (1 = planes [hi | lo | hi] over the whole K / tap, 2 = blocked: 128-byte blocks [hi(32) | lo(32)] per 32 elements of K)
 
 
 def is_x3(w):
@@ -485,6 +488,7 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
         assert len(rows) == Bo
     esz = q.element_size()
     dcode = L.FFN_BF16X3 if (x3 and q.dtype == torch.float32) else _dt(q)      # split-bf16 arithmetic on fp32 operands
+    descs = []
     for b0 in range(0, Bo, L.ATT_MAXB):
         nb = min(L.ATT_MAXB, Bo - b0)
         d = L.AttnDesc()
@@ -506,6 +510,26 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
                 # the tiled-head rule defaults to the OUTPUT row index, which a row-range launch shifts by b0: pin it
                 hr = sp.hr_row if sp.hr_row is not None else (b0 + b if b0 else None)
                 e.hr_row = 0 if hr is None else hr + 1
+        descs.append((b0, nb, d))
+    # split-bf16 self attention on the ping-pong kernel: K / V^T are split ONCE per call into the bf16 images the kernel stages by LDS-DMA
+    # (ffn_attn_presplit; the kernel's 16 query-block workgroups per (row, head) otherwise each split the whole K / V^T in their key loops)
+    if dcode == L.FFN_BF16X3 and _ATTN_PRESPLIT and Dh == 64 and Sk % 64 == 0 and S >= 128 and k.stride(2) == 1 and vt.stride(2) == 1 \
+            and k.stride(0) == Sk * k.stride(1) and vt.stride(0) == heads * Dh * vt.stride(1):
+        nbuf = CT.create_string_buffer(160)
+        names = []
+        for _, _, d in descs:
+            lib.ffn_attn_kernel_name(dcode, CT.byref(d), nbuf, 160)
+            names.append(nbuf.value.decode())
+        if all("attn_x3p_kernel" in n_ for n_ in names):
+            Bk = k.shape[0]
+            kp = torch.empty(Bk, Sk, 2 * heads * Dh, dtype=torch.bfloat16, device=q.device)
+            vp = torch.empty(Bk, heads * Dh, 2 * Sk, dtype=torch.bfloat16, device=q.device)
+            L.check(_timed("attn_presplit_kernel", 0.0, 16.0 * Bk * Sk * heads * Dh,
+                           lambda: lib.ffn_attn_presplit(_stream(), k.data_ptr(), vt.data_ptr(), kp.data_ptr(), vp.data_ptr(), Bk, Sk, heads, k.stride(1), vt.stride(1))),
+                    "ffn_attn_presplit")
+            for _, _, d in descs:
+                d.k, d.vt, d.kv_pair = kp.data_ptr(), vp.data_ptr(), 1
+    for b0, nb, d in descs:
         if _PROF is None:
             L.check(lib.ffn_attn(_stream(), dcode, CT.byref(d)), "ffn_attn")
         else:

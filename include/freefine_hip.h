@@ -172,7 +172,8 @@ typedef struct ffn_attn_desc {
     int npass;
     int out_pair;       /* FFN_BF16X3 with D <= 64 only: out is the bf16 PAIR form [Bo][S][ldo] of rows of ldo/2 columns (layout: FFN_BF16X3 above), the A operand of
                            the to_out projection's FFN_BF16X3 GEMM; 0 = fp32 rows */
-    int reserved;
+    int kv_pair;        /* FFN_BF16X3 launches that run attn_x3p_kernel (ffn_attn_kernel_name says so) only: k / vt are the PRE-SPLIT bf16 images
+                           ffn_attn_presplit wrote (ldk / ldvt ignored); 0 = fp32 k / vt */
     ffn_attn_entry e[FFN_ATT_MAXP * FFN_ATT_MAXB]; /* entry (p,b) at p*FFN_ATT_MAXB + b */
 } ffn_attn_desc;
 int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d);
@@ -185,6 +186,12 @@ int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d);
  * summation order.  FFN_ATTN_PP=0 in the environment forces attn_kernel.
  * bf16 launches with D = 64, Sk <= 96 and ONE pass whose entries carry no key mask / selector / per-query weight (the text
  * cross-attention) run xattn_kernel (attention_x.h: K and V^T of a (row, head) in a wave's registers); FFN_ATTN_X=0 disables it. */
+/* fp32 K [rows][Sk][ldk] (heads * 64 columns) and V^T [rows][heads * 64][ldvt] -> the bf16 images attn_x3p_kernel stages by LDS-DMA when
+ * desc.kv_pair = 1: k_pair [rows][Sk][heads][hi(64) | lo(64)], vt_pair [rows][heads * 64][Sk / 64][hi(64 keys) | lo(64 keys)] (each as many bytes
+ * as its fp32 source; Sk % 64 == 0, head dim 64).  Once per attention call: the kernel's 16 query-block workgroups per (row, head) otherwise each
+ * split the whole K / V^T in their key loops (16-25 % of the launch).  Reference call sites: the self-attention of the hooked Attention.forward,
+ * src/utils/attention.py:394-404, 1043-1091. */
+int ffn_attn_presplit(void* stream, const float* k, const float* vt, void* k_pair, void* vt_pair, int rows, int Sk, int heads, int ldk, int ldvt);
 /* padded head dim / query fragments per wave of the instantiation ffn_attn dispatches for head dim D */
 int ffn_attn_variant(int dtype, int D, int* dp, int* qf);
 /* the kernel instantiation ffn_attn launches for this problem, spelled like rocprofv3's kernel trace */

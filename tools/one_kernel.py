@@ -1,5 +1,5 @@
 """Run ONE kernel shape repeatedly (for rocprofv3 --pmc passes).  python tools/one_kernel.py conv 64 320 320 | gemm M K N | geglu M K N | attn S C heads passes
-ONE_B = batch rows (conv / attn); ONE_MODE = bf16 (default) | x3 (split-bf16: fp32 activations, FFN_BF16X3 weights / attn_x3_kernel)"""
+ONE_B = batch rows (conv / attn); ONE_MODE = bf16 (default) | x3 (split-bf16: fp32 activations, FFN_BF16X3 weights / attn_x3_kernel); ONE_SPLITK = forced K slices (conv)"""
 import os
 import sys
 
@@ -21,7 +21,8 @@ if kind == "conv":
     w = ops.pack_conv3x3(rnd(cout, cin, 3, 3, scale=(9 * cin) ** -0.5), dt, x3=X3)
     b = torch.zeros(cout, device=dev)
     xin = ops.split_pair(x, cin) if X3 else x            # (the UNet's norms hand the convolutions pair rows)
-    fn = lambda: ops.conv3x3(xin, w, b, B, hw, hw, cin)
+    SK = int(os.environ.get("ONE_SPLITK", 0))              # 0 = the library's choice (tuner), k = force k K-slices
+    fn = lambda: ops.conv3x3(xin, w, b, B, hw, hw, cin, splitk=SK)
 elif kind == "geglu":
     M, K, N = map(int, sys.argv[2:5])       # N = packed hidden | gate columns
     x = rnd(M, K)
