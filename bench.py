@@ -17,7 +17,7 @@ all ranks / max-over-ranks time.
 The HEADLINE mode is `--dtype bf16x3` (split-bf16: fp32 storage, every GEMM / attention product on three bf16 MFMAs per term): the fastest
 mode that holds the north star's 1e-3 latent tolerance on the metric's own schedules -- tests/test_pipeline_gpu.py gates it (and the f32 mode)
 at 1e-3 ABSOLUTE against reference-generated N = 50 trajectories (G9: start_step 0 / 35 / 15 / 1) and against full-size SD-2.1 oracle
-trajectories at N = 50 (G10: start_step 35 and 0).  The bf16 mode (4.4 images/s in round 3) does NOT hold that tolerance and is reported under
+trajectories at N = 50 (G10: edit hook at start_step 35 and 0, bg-gen hook at 1, compose hook at 15).  The bf16 mode (4.4 images/s in round 3) does NOT hold that tolerance and is reported under
 `fast_modes`, never as `value`.  Weights: seeded default-init tensors + freefine_amd.weights.plant_denoiser_path, so that the 50-step
 trajectory is a denoising one with O(1) latents (with purely random weights nothing removes the DDPM noise and |latent| grows 14.6x).
 The text encoder inside the timed region is a real-size CLIP-shaped transformers model on the device; its prompt cache is emptied before every
@@ -253,8 +253,11 @@ def parity_leg(args, device, model):
     global _F32_TRAJ
     out = {"tolerance_latent_linf": 1e-3,
            "gates": ("tests/test_pipeline_gpu.py::test_metric_schedules_n50_vs_reference_golden (tiny topology, N=50, start_step 0/35/15, bg-gen 1, "
-                     "compose 15: reference-generated, f32 + bf16x3) and ::test_full_size_n50_schedules_vs_oracle_fixture (SD-2.1 topology 64x64, N=50, "
-                     "start_step 35 and 0: oracle-generated, f32 + bf16x3), absolute latent L-inf <= 1e-3 at every step")}
+                     "compose 15: reference-generated, f32 + bf16x3), ::test_full_size_n50_schedules_vs_oracle_fixture (SD-2.1 topology 64x64, N=50, "
+                     "start_step 35 and 0, N=20: oracle-generated, f32 + bf16x3) and ::test_full_size_n50_other_hooks_vs_oracle_fixture (the same topology "
+                     "under the bg-gen hook at start_step 1 and the compose hook with R = 2 references at start_step 15), absolute latent L-inf <= 1e-3 at "
+                     "every step; profiles/r5_planted_gain_sensitivity.txt: the headline mode's deviation over this schedule at planted gains 0 / 0.5 / 1 / 3 "
+                     "(2-3e-5 of |latent| max at every gain; bf16: 1-2.5e-2)")}
     rec, m32 = timed_mode(args, device, "f32", max(1, args.extra_steps // 3))      # (0.4-0.5 images/s: one timed step of the headline's batch layout)
     _F32_TRAJ = ref = one_image_trajectory(m32, args)
     del m32

@@ -1184,3 +1184,66 @@ def test_ffn_attn_vs_reference_g1_fixture(gpu, mode):
                 s1, _ = g[f"c{ci}_{name}_sum"]
                 assert abs(o.double().sum().item() - s1) < 2e-3 * (1 + abs(s1)), (ci, name)
     print(f"ffn_attn vs the reference's G1 outputs, {mode}: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+
+
+@pytest.mark.parametrize("S,heads,passes", [(4096, 5, 2), (1024, 10, 1), (256, 20, 2)])
+def test_x3_attention_presplit_kv_is_bit_identical(gpu, monkeypatch, S, heads, passes):
+    """Round 5: split-bf16 self attention with K / V^T pre-split ONCE per call (ffn_attn_presplit: bf16 hi / lo images staged by LDS-DMA in
+    attn_x3p_kernel<., PAIRKV = true>) against the same kernel splitting the fp32 tiles inside its key loop: the split values, the MFMA order and
+    the softmax are the same, so the results must agree BIT FOR BIT -- masked two-pass TCA tables (key mask, query selector, tiled-head rule,
+    device-scalar blend) and the plain pass, rings wrapping 64 / 16 / 4 times.  Both against fp64 as well."""
+    import ctypes
+    from freefine_amd import _lib, ops
+    from freefine_amd._lib import ATT_HEAD_RULE
+    g = torch.Generator().manual_seed(S * 3 + heads)
+    B, D = 4, 64
+    Cc = heads * D
+    q, k, v = (rnd((B, S, Cc), torch.float32, gpu, g) for _ in range(3))
+    vt = ops.transpose(v)
+    scale = D ** -0.5
+    cg_dev = torch.tensor([0.35], dtype=torch.float32, device=gpu)
+    if passes == 2:
+        km = (torch.rand(S, generator=g) > 0.7).to(torch.uint8).to(gpu)
+        qs = (torch.rand(S, generator=g) > 0.5).to(torch.uint8).to(gpu)
+        P = [[ops.AttnEntrySpec(b, b | 1, 0.0, 1.0, kmask=km, qsel=qs, flags=ATT_HEAD_RULE) for b in range(B)], [ops.AttnEntrySpec(b, b, 1.0, -1.0) for b in range(B)]]
+    else:
+        P = None
+    outs = {}
+    for pre in (True, False):
+        monkeypatch.setattr(ops, "_ATTN_PRESPLIT", pre)
+        outs[pre] = ops.attention(q, k, vt, heads, scale, P, w_dev=cg_dev, x3=True)
+    assert torch.equal(outs[True], outs[False])
+    d = _lib.AttnDesc()
+    d.Bo, d.S, d.Sk, d.heads, d.D, d.npass, d.ldo, d.kv_pair = B, S, S, heads, D, 1, Cc, 1
+    for b in range(B):
+        d.e[b].q_row, d.e[b].kv_row, d.e[b].w_const = b, b, 1.0
+    name = ctypes.create_string_buffer(160)
+    _lib.load().ffn_attn_kernel_name(_lib.FFN_BF16X3, ctypes.byref(d), name, 160)
+    assert b"attn_x3p_kernel<false, true>" in name.value, name.value
+    if passes == 1:
+        ref = torch.stack([_ref_attention_gpu(q[b].double(), k[b].double(), v[b].double(), heads, scale) for b in range(B)])
+        assert relerr(outs[True], ref) < X3_TOL
+
+
+def test_x3_pair_producers_write_the_blocked_layout(gpu):
+    """every producer of split-bf16 pair rows writes the layout ffn_split_pair writes (128-byte blocks [hi(32) | lo(32)] for C % 32 == 0):
+    GroupNorm (three-launch and fused forms), LayerNorm, the GEGLU projection's pair output and the attention output -- each against the split
+    of its own fp32 result."""
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for B, HW, C in ((2, 4096, 320), (3, 64, 1280)):
+        x = rnd((B, HW, C), torch.float32, gpu, g)
+        ga, be = torch.randn(C, generator=g).to(gpu), torch.randn(C, generator=g).to(gpu)
+        for silu in (False, True):
+            f = ops.groupnorm(x, ga, be, 32, 1e-5, silu=silu)
+            p = ops.groupnorm(x, ga, be, 32, 1e-5, silu=silu, pair=True)
+            assert ops.pair_width(p) == C and torch.equal(p, ops.split_pair(f, C))
+        f, p = ops.layernorm(x, ga, be), ops.layernorm(x, ga, be, pair=True)
+        assert ops.pair_width(p) == C and torch.equal(p, ops.split_pair(f, C))
+    M, K, Fh = 4096, 320, 1280
+    x = rnd((M, K), torch.float32, gpu, g)
+    w = rnd((2 * Fh, K), torch.float32, gpu, g, K ** -0.5)
+    wp, bp = ops.pack_geglu(w, torch.randn(2 * Fh, generator=g).to(gpu), torch.float32, x3=True)
+    f = ops.linear(x, wp, bp, geglu=True)
+    p = ops.linear(x, wp, bp, geglu=True, out_pair=True)
+    assert ops.pair_width(p) == Fh and relerr(pair_value(p, Fh), f.double()) < 1e-6      # (hi + lo carries the fp32 result to 2^-17)
