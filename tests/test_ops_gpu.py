@@ -1246,4 +1246,4 @@ def test_x3_pair_producers_write_the_blocked_layout(gpu):
     wp, bp = ops.pack_geglu(w, torch.randn(2 * Fh, generator=g).to(gpu), torch.float32, x3=True)
     f = ops.linear(x, wp, bp, geglu=True)
     p = ops.linear(x, wp, bp, geglu=True, out_pair=True)
-    assert ops.pair_width(p) == Fh and relerr(pair_value(p, Fh), f.double()) < 1e-6      # (hi + lo carries the fp32 result to 2^-17)
+    assert ops.pair_width(p) == Fh and relerr(pair_value(p, Fh), f.double()) < X3_TOL      # (two kernels, two erf forms: the layout is what is checked)
