@@ -80,6 +80,7 @@ SYMBOLS = {
     "ffn_device_info": (_i, [_i, C.c_char_p, _i]),
     "ffn_graph_launch": (_i, [_vp, _vp]),
     "ffn_igemm": (_i, [_vp, _i, C.POINTER(IgemmDesc)]),
+    "ffn_conv3x3_n4": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "ffn_split_pair": (_i, [_vp, _vp, _vp, _l, _i, _i]),
     "ffn_groupnorm_f8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _f, _vp, _vp, _vp]),
     "ffn_attn": (_i, [_vp, _i, C.POINTER(AttnDesc)]),

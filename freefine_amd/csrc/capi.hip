@@ -15,6 +15,7 @@
 #include "attention_x3.h"
 #include "attention_x3p.h"
 #include "attention_xx3.h"
+#include "conv_small.h"
 #include "elementwise.h"
 #include "igemm.h"
 #include "igemm_p8.h"
@@ -876,6 +877,24 @@ extern "C" int ffn_split_pair(void* stream, const float* src, void* dst, long ro
     REQUIRE(aligned16(src) && aligned16(dst), "split_pair: pointers must be 16-byte aligned");
     LAUNCH(split_pair_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, (bf16*)dst, rows, C, ld_src);
     return check_launch("split_pair");
+}
+extern "C" int ffn_conv3x3_n4(void* stream, int dtype, const void* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cin) {
+    REQUIRE(dtype == FFN_F32 || dtype == FFN_BF16, "conv3x3_n4: fp32 or bf16 activations");
+    REQUIRE(x && w && out && aligned16(x) && aligned16(w) && aligned16(out) && (!bias || aligned16(bias)), "conv3x3_n4: null / unaligned pointer");
+    REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cin <= 448, "conv3x3_n4: B=%d H=%d W=%d Cin=%d (Cin %% 16 == 0, <= 448)", B, H, W, Cin);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long npix = (long)B * H * W;
+    const int lds = 36 * Cin * 4;
+    dim3 grid((unsigned)((npix + 63) / 64));
+    int rc;
+    if (dtype == FFN_F32) {
+        if ((rc = set_lds(conv3x3_n4_kernel<float>, lds))) return rc;
+        LAUNCH(conv3x3_n4_kernel<float>, grid, dim3(256), lds, s, (const float*)x, w, bias, out, B, H, W, Cin);
+    } else {
+        if ((rc = set_lds(conv3x3_n4_kernel<bf16>, lds))) return rc;
+        LAUNCH(conv3x3_n4_kernel<bf16>, grid, dim3(256), lds, s, (const bf16*)x, w, bias, out, B, H, W, Cin);
+    }
+    return check_launch("conv3x3_n4");
 }
 extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
     REQUIRE(d, "igemm: null descriptor");

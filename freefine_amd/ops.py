@@ -139,6 +139,27 @@ def pack_conv3x3(w, dtype, cin_pad=None, x3=False):
     return pack_linear(w2.reshape(cout, 9 * cp), dtype)
 
 
+def pack_conv3x3_n4(w):
+    """[4, Cin, 3, 3] -> fp32 [4, 9 * Cin] in (ky, kx, ci) order: the weights of ffn_conv3x3_n4 (the UNet's conv_out on the vector ALU)"""
+    assert w.shape[0] == 4 and w.shape[2:] == (3, 3)
+    return w.float().permute(0, 2, 3, 1).reshape(4, -1).contiguous()
+
+
+def conv3x3_n4_eligible(cout, cin):
+    return cout == 4 and cin % 16 == 0 and cin <= 448 and os.environ.get("FFN_CONV_N4", "1") != "0"
+
+
+def conv3x3_n4(x, w4, bias, B, H, W, Cin):
+    """3x3 / stride 1 / pad 1 convolution with four output channels as a direct fp32 convolution (ffn_conv3x3_n4): x [B, H*W, Cin] fp32 or
+    bf16, w4 from pack_conv3x3_n4; returns fp32 [B, H*W, 4]"""
+    lib = L.load()
+    assert x.is_contiguous() and x.shape[-1] == Cin and x.dtype in (torch.float32, torch.bfloat16)
+    out = torch.empty(B, H * W, 4, dtype=torch.float32, device=x.device)
+    L.check(_timed("conv3x3_n4_kernel", 2.0 * B * H * W * 4 * 9 * Cin, x.element_size() * x.numel() + 16.0 * B * H * W,
+                   lambda: lib.ffn_conv3x3_n4(_stream(), _dt(x), x.data_ptr(), w4.data_ptr(), _p(bias), out.data_ptr(), B, H, W, Cin)), "ffn_conv3x3_n4")
+    return out
+
+
 def up2x_eligible(cin, cout, rows):
     """does the sub-pixel form of `nearest-2x upsample -> 3x3 conv` apply?  (bf16 ping-pong tiles: whole 64-channel chunks, N a tile multiple,
     at least one 192-row tile of LOW-resolution pixels)"""

@@ -151,6 +151,9 @@ class HipUNet:
             self.up.append(blk)
         self.norm_out = (self._f32(st["conv_norm_out.weight"]), self._f32(st["conv_norm_out.bias"]))
         self.conv_out = self._conv(st, "conv_out")
+        # four output channels: a direct fp32 convolution on the vector ALU instead of 1/32 of an MFMA tile (ops.conv3x3_n4, round 5)
+        wco = st["conv_out.weight"]
+        self.conv_out_n4 = ops.pack_conv3x3_n4(wco.to(self.device)) if ops.conv3x3_n4_eligible(wco.shape[0], wco.shape[1]) else None
         # conv_out has out_channels (4) outputs: fine for the kernel (N % 4 == 0)
         wcat = torch.cat([w for w, _ in temb_list], 0).to(self.device)
         self.temb_w = ops.pack_linear(wcat, self.dtype, self.x3)
@@ -781,8 +784,12 @@ class HipUNet:
                     x = ops.conv3x3(x, blk.up[0], blk.up[1], B, H, W, C, upsample=True, out=cat_dst(C, 4 * H * W))
                 H, W = 2 * H, 2 * W
         C = x.shape[-1]
-        x = self._gn(x, self.norm_out, cfg.norm_eps, True)
-        eps = ops.conv3x3(x, self.conv_out[0], self.conv_out[1], B, H, W, C, out_f32=True)
+        if self.conv_out_n4 is not None:
+            x = ops.groupnorm(x, self.norm_out[0], self.norm_out[1], cfg.norm_num_groups, cfg.norm_eps, silu=True)      # plain activations (no pair rows)
+            eps = ops.conv3x3_n4(x, self.conv_out_n4, self.conv_out[1], B, H, W, C)
+        else:
+            x = self._gn(x, self.norm_out, cfg.norm_eps, True)
+            eps = ops.conv3x3(x, self.conv_out[0], self.conv_out[1], B, H, W, C, out_f32=True)
         eps = ops.nhwc_to_nchw_f32(eps, cfg.out_channels, H, W)
         self._in_phase_a = False
         if B != BB:                                           # dropped tail / stored K / V: the reference rows' eps is not computed (zeros)

@@ -101,6 +101,10 @@ int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
  *   out, residual   fp32 (FFN_IG_OUT_F32 is implied); bias / rowbias fp32 as always; GEGLU, SILU, transposed output, split-K as in bf16.
  * K in the descriptor is the REAL contraction length (dense K, conv 9*Cin). */
 int ffn_split_pair(void* stream, const float* src, void* dst, long rows, int C, int ld_src);
+/* 3x3 / stride 1 / pad 1 convolution with FOUR output channels (the UNet's conv_out): x NHWC [B][H*W][Cin] (FFN_F32 or FFN_BF16 elements), w fp32
+ * [4][9][Cin] ((ky, kx, ci) order), bias fp32 [4] or NULL, out fp32 [B][H*W][4].  Direct fp32 convolution on the vector ALU (exact fp32 products in
+ * every mode) instead of 1/32 of an MFMA tile; Cin % 16 == 0, Cin <= 448 (weights in LDS). */
+int ffn_conv3x3_n4(void* stream, int dtype, const void* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cin);
 /* FFN_FP8 (3x3 convolutions of the bf16 fast mode, reported beside it -- not a parity mode): A = e4m3 bytes NHWC [B][Hin][Win][Cin] with
  * Cin a multiple of 16 (the ping-pong tile: of 128; ffn_groupnorm_f8 writes such a tensor, channels zero-padded), W = e4m3 [N][Kpad]
  * in the usual (ky, kx, ci) order, K = 9 * Cin; out / residual bf16, bias / rowbias fp32.  Both operands carry power-of-two scales (the

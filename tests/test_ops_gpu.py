@@ -1247,3 +1247,22 @@ def test_x3_pair_producers_write_the_blocked_layout(gpu):
     f = ops.linear(x, wp, bp, geglu=True)
     p = ops.linear(x, wp, bp, geglu=True, out_pair=True)
     assert ops.pair_width(p) == Fh and relerr(pair_value(p, Fh), f.double()) < X3_TOL      # (two kernels, two erf forms: the layout is what is checked)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,Cin", [(3, 64, 64, 320), (2, 16, 24, 32), (1, 5, 7, 128)])
+def test_conv3x3_n4_direct(gpu, dtype, B, H, W, Cin):
+    """the UNet's conv_out (3x3, four output channels) as a direct fp32 convolution on the vector ALU (ffn_conv3x3_n4, round 5) against
+    torch's conv2d in fp64: exact fp32 products in every mode -- 1e-6 of the output scale on fp32 activations, the bf16 INPUT rounding only on bf16."""
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + Cin)
+    x = rnd((B, Cin, H, W), torch.float32, gpu, g)
+    w = rnd((4, Cin, 3, 3), torch.float32, gpu, g, (9 * Cin) ** -0.5)
+    b = torch.randn(4, generator=g).to(gpu)
+    xin = x.to(dtype)
+    ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1).reshape(B, H * W, 4)
+    out = ops.conv3x3_n4(xin.permute(0, 2, 3, 1).reshape(B, H * W, Cin).contiguous(), ops.pack_conv3x3_n4(w), b, B, H, W, Cin)
+    assert out.dtype == torch.float32 and out.shape == (B, H * W, 4)
+    err = relerr(out, ref)
+    print(f"conv3x3_n4 {dtype} B={B} {H}x{W} Cin={Cin}: {err:.2e}")
+    assert err < 2e-6
