@@ -13,15 +13,15 @@
 #include "attention_x.h"
 #include "attention_x3.h"
 
-template <int NKF>
-__global__ __launch_bounds__(256) void xattn_x3_kernel(const AttnParams p, int wgs_per_pair, int blocks_per_wave) {
+template <int NKF, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void xattn_x3_kernel(const AttnParams p, int wgs_per_pair, int blocks_per_wave) {
     constexpr int NKS = (NKF + 1) / 2;
     constexpr int QF = 2;
     constexpr int NFR = NKF * 2 + 4 * NKS;            // fragments per pass (K: NKF x 2 d-steps, V^T: 4 d-fragments x NKS key steps); x 2 images (hi, lo)
     constexpr int OOB = (int)0x80000000;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = blockIdx.x / wgs_per_pair, chunk = (blockIdx.x - pair * wgs_per_pair) * 4 + wave;
+    const int pair = blockIdx.x / wgs_per_pair, chunk = (blockIdx.x - pair * wgs_per_pair) * NW + wave;
     const int b = pair / p.heads, head = pair - b * p.heads;
     const int l15 = lane & 15, g = lane >> 4;
     const int C = p.heads * 64;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void xattn_x3_kernel(const AttnParams p, int w
     for (int ps = 0; ps < p.npass; ++ps) {
         const AttnEntry& e = p.e[ps * ATT_MAXB + b];
         if (e.w_const == 0.f && e.w_slope == 0.f) continue;
-        for (int i = wave; i < NFR; i += 4) {
+        for (int i = wave; i < NFR; i += NW) {
             f32x4 a, c;
             if (i < 2 * NKF) {                        // K fragment (key fragment f, d-step ks): lane = key 16 f + l15, d = 32 ks + 8 g .. + 7
                 const int f = i >> 1, ks = i & 1;
@@ -72,6 +72,35 @@ __global__ __launch_bounds__(256) void xattn_x3_kernel(const AttnParams p, int w
     int nblk = nblk_total - blk0;
     if (nblk > blocks_per_wave) nblk = blocks_per_wave;
 
+    // work items = (query block, active pass) in order; the Q rows (and per-query weights) of the NEXT item are requested before the current
+    // item's arithmetic starts, so a wave's HBM latency hides behind its own MFMA / softmax work (one or two waves per SIMD run here)
+    auto active_from = [&](int ps) {
+        for (; ps < p.npass; ++ps) {
+            const AttnEntry& e = p.e[ps * ATT_MAXB + b];
+            if (e.w_const != 0.f || e.w_slope != 0.f) break;
+        }
+        return ps;
+    };
+    f32x4 qraw[QF][2][2];
+    float wqn[QF];
+    auto request_q = [&](int blk, int ps) {
+        const AttnEntry& e = p.e[ps * ATT_MAXB + b];
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            const int qrow = blk * 32 + 16 * f + l15;
+            const int vo = qrow < p.S ? qvo : OOB;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int so = ((e.q_row * p.S + blk * 32 + 16 * f) * p.ldq + head * 64 + 32 * ks) * 4;
+                qraw[f][ks][0] = ld4(rq, vo, so);
+                qraw[f][ks][1] = ld4(rq, vo, so + 16);
+            }
+            wqn[f] = (e.wq && qrow < p.S) ? e.wq[qrow] : 1.f;
+        }
+    };
+    const int ps0 = active_from(0);
+    if (nblk > 0 && ps0 < p.npass) request_q(blk0, ps0);
+
     for (int ib = 0; ib < nblk; ++ib) {
         const int blk = blk0 + ib;
         f32x4 acc[4][QF];
@@ -79,24 +108,21 @@ __global__ __launch_bounds__(256) void xattn_x3_kernel(const AttnParams p, int w
         for (int df = 0; df < 4; ++df)
 #pragma unroll
             for (int qf = 0; qf < QF; ++qf) acc[df][qf] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int ps = 0; ps < p.npass; ++ps) {
+        for (int ps = ps0; ps < p.npass;) {
             const AttnEntry& e = p.e[ps * ATT_MAXB + b];
-            if (e.w_const == 0.f && e.w_slope == 0.f) continue;
+            const int ps_next = active_from(ps + 1);
             const float w = e.w_const + (e.w_slope != 0.f ? e.w_slope * *p.w_dev : 0.f);
             const char* img = smem + ps * 2 * NFR * 1024 + lane * 16;
             u32x4 qh[QF][2], ql[QF][2];
             float wql[QF];
 #pragma unroll
             for (int f = 0; f < QF; ++f) {
-                const int qrow = blk * 32 + 16 * f + l15;
-                const int vo = qrow < p.S ? qvo : OOB;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int so = ((e.q_row * p.S + blk * 32 + 16 * f) * p.ldq + head * 64 + 32 * ks) * 4;
-                    x3_split8(ld4(rq, vo, so), ld4(rq, vo, so + 16), qh[f][ks], ql[f][ks]);
-                }
-                wql[f] = (e.wq && qrow < p.S) ? e.wq[qrow] : 1.f;
+                for (int ks = 0; ks < 2; ++ks) x3_split8(qraw[f][ks][0], qraw[f][ks][1], qh[f][ks], ql[f][ks]);
+                wql[f] = wqn[f];
             }
+            if (ps_next < p.npass) request_q(blk, ps_next);
+            else if (ib + 1 < nblk) request_q(blk + 1, ps0);
             f32x4 st[NKF][QF];
 #pragma unroll
             for (int f = 0; f < NKF; ++f) {
@@ -179,17 +205,36 @@ __global__ __launch_bounds__(256) void xattn_x3_kernel(const AttnParams p, int w
                     acc[df][qf] += o * sc[qf];
                 }
             }
+            ps = ps_next;
         }
-        // lane (l15, g) holds O[q = 16 qf + l15][d = 16 df + 4 g + r]: four consecutive columns of one output row
+        // lane (l15, g) holds O[q = 16 qf + l15][d = 16 df + 4 g + r]: four consecutive columns.  A swap between the 16-lane rows (v_permlane16_swap on
+        // the fragment pair (2 j, 2 j + 1)) leaves it with EIGHT consecutive columns, 16 (g & 1) + 8 (g >> 1) .., of the 32-column block j: 16-byte
+        // stores, half as many (-8 % on the 64x64-level launch; the GEMM epilogues' wave permutation on top of it measured no further gain here)
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) {
             const int q = blk * 32 + 16 * qf + l15;
-            if (q >= p.S) continue;
 #pragma unroll
-            for (int df = 0; df < 4; ++df) {
-                const float vv[4] = {acc[df][qf][0], acc[df][qf][1], acc[df][qf][2], acc[df][qf][3]};
-                if (p.out_pair) store_pair_row4(reinterpret_cast<bf16*>(p.out) + ((long)b * p.S + q) * p.ldo, head * 64 + 16 * df + 4 * g, p.ldo / 2, vv);
-                else store4(reinterpret_cast<float*>(p.out) + ((long)b * p.S + q) * p.ldo + head * 64 + 16 * df + 4 * g, vv);
+            for (int j = 0; j < 2; ++j) {
+                f32x4 x, y;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * j][qf][r]), __float_as_uint(acc[2 * j + 1][qf][r]), false, false);
+                    x[r] = __uint_as_float(sw[0]);
+                    y[r] = __uint_as_float(sw[1]);
+                }
+                if (q >= p.S) continue;
+                const int col = head * 64 + 32 * j + 16 * (g & 1) + 8 * (g >> 1);
+                if (p.out_pair) {                     // C = 64 heads: always the blocked pair form (common.h pair_pos)
+                    u32x4 hi, lo;
+                    x3_split8(x, y, hi, lo);
+                    bf16* row = reinterpret_cast<bf16*>(p.out) + ((long)b * p.S + q) * p.ldo + pair_pos(col, C);
+                    *reinterpret_cast<u32x4*>(row) = hi;
+                    *reinterpret_cast<u32x4*>(row + 32) = lo;
+                } else {
+                    float* row = reinterpret_cast<float*>(p.out) + ((long)b * p.S + q) * p.ldo + col;
+                    *reinterpret_cast<f32x4*>(row) = x;
+                    *reinterpret_cast<f32x4*>(row + 4) = y;
+                }
             }
         }
     }

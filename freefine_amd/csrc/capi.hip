@@ -1072,22 +1072,30 @@ static int launch_xattn(hipStream_t s, const ffn_attn_desc& d, int nkf, int mult
     return check_launch("attn(cross)");
 }
 // the split-bf16 form: always the LDS-fragment-image structure (hi and lo images of every active pass: 2 x nfr KiB per pass)
-static int launch_xattn_x3(hipStream_t s, const ffn_attn_desc& d, int nkf) {
+template <int NW>
+static int launch_xattn_x3_nw(hipStream_t s, const ffn_attn_desc& d, int nkf, int waves_per_cu) {
     const int pairs = d.Bo * d.heads, nblk = (d.S + 31) / 32;
-    int wpp = (8 * device_cus()) / pairs / 4;         // workgroups per (row, head)
+    int wpp = (waves_per_cu * device_cus()) / pairs / NW;         // workgroups per (row, head)
     if (wpp < 1) wpp = 1;
-    if (wpp > (nblk + 3) / 4) wpp = (nblk + 3) / 4;
-    const int bpw = (nblk + 4 * wpp - 1) / (4 * wpp);
-    wpp = (nblk + 4 * bpw - 1) / (4 * bpw);
+    if (wpp > (nblk + NW - 1) / NW) wpp = (nblk + NW - 1) / NW;
+    const int bpw = (nblk + NW * wpp - 1) / (NW * wpp);
+    wpp = (nblk + NW * bpw - 1) / (NW * bpw);
     const int nfr = nkf * 2 + 4 * ((nkf + 1) / 2);
     const int lds = d.npass * 2 * nfr * 1024;
     if (lds > 160 * 1024) return -1;                  // (more passes than fit: the caller takes the generic kernel)
     dim3 grid(pairs * wpp);
     int rc;
-    if (nkf == 2) { if ((rc = set_lds(xattn_x3_kernel<2>, lds))) return rc; LAUNCH(xattn_x3_kernel<2>, grid, dim3(256), lds, s, d, wpp, bpw); }
-    else if (nkf == 5) { if ((rc = set_lds(xattn_x3_kernel<5>, lds))) return rc; LAUNCH(xattn_x3_kernel<5>, grid, dim3(256), lds, s, d, wpp, bpw); }
-    else { if ((rc = set_lds(xattn_x3_kernel<6>, lds))) return rc; LAUNCH(xattn_x3_kernel<6>, grid, dim3(256), lds, s, d, wpp, bpw); }
+    if (nkf == 2) { if ((rc = set_lds(xattn_x3_kernel<2, NW>, lds))) return rc; LAUNCH((xattn_x3_kernel<2, NW>), grid, dim3(64 * NW), lds, s, d, wpp, bpw); }
+    else if (nkf == 5) { if ((rc = set_lds(xattn_x3_kernel<5, NW>, lds))) return rc; LAUNCH((xattn_x3_kernel<5, NW>), grid, dim3(64 * NW), lds, s, d, wpp, bpw); }
+    else { if ((rc = set_lds(xattn_x3_kernel<6, NW>, lds))) return rc; LAUNCH((xattn_x3_kernel<6, NW>), grid, dim3(64 * NW), lds, s, d, wpp, bpw); }
     return check_launch("attn(cross, split-bf16)");
+}
+static int launch_xattn_x3(hipStream_t s, const ffn_attn_desc& d, int nkf) {
+    // 8 waves per workgroup where the fragment images are large against a workgroup's share of the queries (two passes: 88 KiB, one workgroup per CU
+    // either way) or the launch is long; 4 (two workgroups per CU) for the short single-pass launches (profiles/r5_xattn_x3_waves_and_stores.txt)
+    static const int nw_env = [] { const char* e = getenv("FFN_XATT_NW"); return e ? atoi(e) : 0; }();
+    const int nw = nw_env ? nw_env : ((d.npass >= 2 || d.S >= 4096) ? 8 : 4);
+    return nw == 8 ? launch_xattn_x3_nw<8>(s, d, nkf, 8) : launch_xattn_x3_nw<4>(s, d, nkf, 8);
 }
 static bool xattn_x3_fits(const ffn_attn_desc& d, int nkf) { return d.npass * 2 * (nkf * 2 + 4 * ((nkf + 1) / 2)) * 1024 <= 160 * 1024; }
 static bool attn_has_masks(const ffn_attn_desc& d) {
@@ -1114,7 +1122,7 @@ extern "C" int ffn_attn_kernel_name(int dtype, const ffn_attn_desc* d, char* buf
     if (dtype == FFN_BF16X3 && d->D <= 64) {
         if (const int nkf = xattn_nkf(*d, nullptr, 4)) {
             if (xattn_x3_fits(*d, nkf)) {
-                snprintf(buf, len, "void xattn_x3_kernel<%d>(ffn_attn_desc, int, int)", nkf);
+                snprintf(buf, len, "void xattn_x3_kernel<%d, %d>(ffn_attn_desc, int, int)", nkf, (d->npass >= 2 || d->S >= 4096) ? 8 : 4);
                 return FFN_OK;
             }
         }

@@ -1,4 +1,4 @@
-"""Run ONE kernel shape repeatedly (for rocprofv3 --pmc passes).  python tools/one_kernel.py conv 64 320 320 | gemm M K N | geglu M K N | attn S C heads passes
+"""Run ONE kernel shape repeatedly (for rocprofv3 --pmc passes).  python tools/one_kernel.py conv 64 320 320 | gemm M K N | geglu M K N | attn S C heads passes | xattn S C heads passes
 ONE_B = batch rows (conv / attn); ONE_MODE = bf16 (default) | x3 (split-bf16: fp32 activations, FFN_BF16X3 weights / attn_x3_kernel); ONE_SPLITK = forced K slices (conv)"""
 import os
 import sys
@@ -36,6 +36,12 @@ elif kind == "gemm":
     w = ops.pack_linear(rnd(N, K, scale=K ** -0.5), dt, x3=X3)
     xin = ops.split_pair(x, K) if X3 else x
     fn = lambda: ops.linear(xin, w, None, K=K)
+elif kind == "xattn":                       # the text cross-attention: 77 keys, V^T rows padded to 80; passes = 2: the two-pass local form with per-query weights
+    S, C, heads, passes = map(int, sys.argv[2:6])
+    q, k, vt = rnd(B, S, C), rnd(B, 77, C), rnd(B, C, 80)
+    wq = torch.rand(S, generator=g).to(dev)
+    P = None if passes == 1 else [[ops.AttnEntrySpec(b, b, 1.0, 0.0, wq=wq) for b in range(B)], [ops.AttnEntrySpec(b, b ^ 1, 1.0, 0.0, wq=wq) for b in range(B)]]
+    fn = lambda: ops.attention(q, k, vt, heads, (C // heads) ** -0.5, P, Sk=77, x3=X3, out_pair=X3)
 else:
     S, C, heads, passes = map(int, sys.argv[2:6])
     q, k, vt = rnd(B, S, C), rnd(B, S, C), rnd(B, C, S)
@@ -48,3 +54,12 @@ else:
 for _ in range(10):
     fn()
 torch.cuda.synchronize()
+if os.environ.get("ONE_TIME"):              # event-timed average over ONE_TIME launches (not under the profiler)
+    n = int(os.environ["ONE_TIME"])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{' '.join(sys.argv[1:])} B={B} mode={'x3' if X3 else 'bf16'}: {e0.elapsed_time(e1) / n * 1e3:.1f} us per call", flush=True)
