@@ -13,7 +13,8 @@ from freefine_amd.weights import synthetic_state, vae_param_shapes  # noqa: E402
 
 dev = torch.device("cuda:0")
 cfg = VAEConfig.preset("sd")
-vae = HipVAE(cfg, synthetic_state(vae_param_shapes(cfg), 1), torch.bfloat16, dev)
+MODE = os.environ.get("VAE_MODE", "bf16")          # bf16 | x3 (the headline mode: fp32 storage, split-bf16 GEMMs)
+vae = HipVAE(cfg, synthetic_state(vae_param_shapes(cfg), 1), torch.float32 if MODE == "x3" else torch.bfloat16, dev, **({"x3": True} if MODE == "x3" else {}))
 img = torch.randint(0, 256, (16, 512, 512, 3), dtype=torch.uint8, device=dev)
 lat = torch.randn(16, 4, 64, 64, device=dev)
 
@@ -38,6 +39,12 @@ for name, fn in (("encode", lambda: vae.encode_mean_scaled(img_u8=img)), ("decod
     fn()
     prof = ops.profile_end()
     rows = sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:8]
-    print(name)
+    tot = sum(v["total_ms"] for v in prof.values())
+    print(name, f"(event-timed eager launches: {tot:.1f} ms)")
     for k, v in rows:
         print(f"   {v['total_ms']:8.2f} ms  {v['calls']:4d} calls  {v['flops'] / max(v['total_ms'], 1e-9) / 1e9:7.0f} TFLOP/s  {k[:110]}")
+
+# the mid-block attention alone (q k^T -> softmax_rows -> P V per image through [S, S] in HBM, vae.py _attention): its share of the bracket
+x = torch.randn(16, 4096, 512, device=dev).to(vae.dtype)
+ta = timeit(lambda: vae._attention(vae.dec_mid.attn, x, 16, 4096))
+print(f"mid-block attention, 16 images: {ta:.2f} ms = {100 * ta / td:.1f} % of the decode, {100 * 3 * ta / (2 * te + td):.1f} % of the bracket (encode and decode have one each)")
