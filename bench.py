@@ -26,7 +26,8 @@ batch of edits, so every step pays for its prompts.
 Extra objects on the JSON line:
   parity        this run's own check: the headline mode's latent trajectory against the f32 mode's over the FULL schedule (absolute L-inf,
                 `passes`), beside the names of the gates that pin both modes to the reference / oracle.
-  fast_modes    bf16 (and with --fp8-leg the e4m3-convolution variant): throughput by the same protocol + the deviation that disqualifies it.
+  fast_modes    bf16 (and with --fp8-leg the e4m3-convolution variant): throughput by the same protocol (at --extra-batch images per UNet batch, like
+                parity.f32_mode: each record names its batch x streams) + the deviation that disqualifies it.
   roofline      the dominant kernel (largest total time of an eagerly executed, HIP-event-timed image in this very process):
                 achieved = algorithmic FLOPs per launch / average launch duration; peak = dense MFMA peak of the dtype.
   cpu_baseline  the CPU oracle (oracle/, "port") timed on this host's cores on a bounded sample of the same workload.
@@ -210,12 +211,13 @@ def deviation(traj, ref):
 
 
 def timed_mode(args, device, mode, steps, fp8=False, base=7000):
-    """throughput of another arithmetic mode by the headline's protocol: same images per UNet batch, same number of HIP streams, one warm-up
+    """throughput of another arithmetic mode by the headline's protocol: --extra-batch images per UNet batch, same number of HIP streams, one warm-up
     pass per stream (tuning, graph capture), then `steps` timed steps between synchronisations.  Returns (record, model)."""
     import copy
     import threading
     a = copy.copy(args)
     a.dtype, a.fp8_conv = mode, fp8
+    a.batch = min(args.batch, args.extra_batch)       # side legs: at most --extra-batch images per UNet batch (the record says which), to bound the run time
     m = build_model(a, device, 0, 1)
     models = [m] + [add_sibling(m) for _ in range(args.concurrent - 1)]
     streams = [torch.cuda.Stream(device=device) for _ in models]
@@ -237,10 +239,10 @@ def timed_mode(args, device, mode, steps, fp8=False, base=7000):
     [t.join() for t in th]
     torch.cuda.synchronize()
     dt = time.time() - t0
-    v = steps * len(models) * args.batch / dt
+    v = steps * len(models) * a.batch / dt
     n = args.num_step - args.start_step
     f_img = n * (2 * F_UNET + 4 * F_UNET + 4 * F_TCA) + F_VAE
-    rec = {"value": round(v, 4), "unit": "images/s", "steps": steps, "images_per_unet_batch": args.batch, "concurrent_streams": len(models),
+    rec = {"value": round(v, 4), "unit": "images/s", "steps": steps, "images_per_unet_batch": a.batch, "concurrent_streams": len(models),
            "whole_path_frac_of_mfma_peak": round(f_img * v / 1e12 / PEAK_TFLOPS[mode], 4), "mfma_peak_tflops": round(PEAK_TFLOPS[mode], 1)}
     del models[1:]
     return rec, m
@@ -367,8 +369,10 @@ def main():
     ap.add_argument("--num-step", dest="num_step", type=int, default=50)
     ap.add_argument("--start-step", dest="start_step", type=int, default=0)
     ap.add_argument("--concurrent", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="independent edits per UNet batch (image-level batching; split-bf16 measures the same "
-                    "throughput at 8 and at 16 per batch, 8 keeps a step -- and the driver's 25-step run -- short)")
+    ap.add_argument("--extra-batch", dest="extra_batch", type=int, default=8, help="images per UNet batch of the f32 / fast-mode side legs (min with --batch)")
+    ap.add_argument("--batch", type=int, default=24, help="independent edits per UNet batch (image-level batching).  24 x 2 streams: the 32x32 level's inversion "
+                    "batches fill 256 CUs without split-K (profiles/r5_batch_x_streams.txt: 8 x 2 1.91, 16 x 2 1.97, 16 x 3 2.01, 24 x 2 2.02 images/s); a step is 48 images, "
+                    "the driver's --steps 20 --warmup 5 about 12 minutes with the side legs at --extra-batch")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-dedup", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")

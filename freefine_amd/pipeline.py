@@ -44,6 +44,14 @@ def _dilate(mask, k):
     return ndimage.maximum_filter(mask.astype(np.uint8), size=(k, k), mode="constant", cval=0)  # == cv2.dilate(ones(k,k))
 
 
+def images_to_u8(images):
+    """[K,3,H,W] float images in [0,1] on the device -> K uint8 HWC numpy arrays.  The reference's `(x.permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8)`
+    (/root/reference/src/demo/model.py:1046-1049) with the fp32 multiply and the truncating cast done on the device: identical bytes, one contiguous
+    768 KB-per-image copy to the host instead of K permuted 3 MB ones."""
+    u8 = (images.detach().float().permute(0, 2, 3, 1) * 255).to(torch.uint8).contiguous().cpu().numpy()
+    return [u8[k] for k in range(u8.shape[0])]
+
+
 class FreeFinePipeline:
     _progress_bar_config = {}
     _warned_ref_cache = False
@@ -256,7 +264,7 @@ class FreeFinePipeline:
     def latent2image(self, latents, return_type="np"):
         image = self.vae.decode_image(latents.detach())
         if return_type == "np":
-            return (image.cpu().permute(0, 2, 3, 1).numpy()[0] * 255).astype(np.uint8)
+            return images_to_u8(image[:1])[0]
         return image
 
     @torch.no_grad()
@@ -785,8 +793,8 @@ class FreeFinePipeline:
             blending=local_text_edit, local_perturbation=local_perturbation, return_intermediates=return_intermediates,
             use_share_attention=use_share_attention, end_scale=end_scale)
         c.reset()
-        to_u8 = lambda im: (im.permute(1, 2, 0).detach().cpu().numpy() * 255).astype(np.uint8)
-        return to_u8(gen_images[0]), to_u8(gen_images[1]), intermediates
+        u8 = images_to_u8(gen_images[:2])
+        return u8[0], u8[1], intermediates
 
     def Details_Preserving_regeneration_compose(self, source_image, inverted_latents, edit_prompt_list, ori_mask_lists, tgt_mask_lists,
                                                 draw_mask, num_steps=100, start_step=30, end_step=10, eta=1, guidance_scale=7.5,
@@ -808,7 +816,7 @@ class FreeFinePipeline:
             cfg_masks_tensor=cfg_m, share_attn=share_attn, method_type=method_type, verbose=verbose,
             local_perturbation=local_perturbation, return_intermediates=return_intermediates, end_scale=end_scale)
         c.reset()
-        return (img.permute(1, 2, 0).detach().cpu().numpy() * 255).astype(np.uint8), intermediates
+        return images_to_u8(img[None])[0], intermediates
 
     def Details_Preserving_regeneration_background(self, ori_img, inverted_latents, edit_prompt, ori_mask, num_steps=100, start_step=30,
                                                    end_step=10, guidance_scale=3.5, eta=1, verbose=False, local_text_edit=True,
@@ -827,7 +835,7 @@ class FreeFinePipeline:
             local_text_edit=local_text_edit, local_perturbation=local_perturbation, return_intermediates=return_intermediates,
             end_scale=end_scale, latent_blended=latent_blended, blend_range=blend_range)
         c.reset()
-        return (gen_images[0].permute(1, 2, 0).detach().cpu().numpy() * 255).astype(np.uint8), intermediates
+        return images_to_u8(gen_images[:1])[0], intermediates
 
     _METHODS = ["tca", "ssa", "sdsa", "mmsa", "mmsa_es"]
 
@@ -987,15 +995,15 @@ class FreeFinePipeline:
             lat_v = latents.view(K, 2, *init.shape[1:])
         for c in ctrls:
             c.reset()
-        to_u8 = lambda im: (im.permute(1, 2, 0).detach().cpu().numpy() * 255).astype(np.uint8)
         self.last_intermediates = inter
         if return_ori:
             images = self.latent2image(latents, return_type="pt")
-            return [(to_u8(images[2 * k]), to_u8(images[2 * k + 1])) for k in range(K)]
+            u8 = images_to_u8(images)
+            return [(u8[2 * k], u8[2 * k + 1]) for k in range(K)]
         # the reference decodes both streams and drops the reference image unless return_ori (model.py:619, 1046-1049): decode only
         # the edited rows (VAE decode is per row: the kept image is unchanged)
         images = self.latent2image(latents[0::2].contiguous(), return_type="pt")
-        return [to_u8(images[k]) for k in range(K)]
+        return images_to_u8(images)
 
 
     @torch.no_grad()
@@ -1078,7 +1086,7 @@ class FreeFinePipeline:
                 c.reset()
             images = self.latent2image(latents[0::2].contiguous(), return_type="pt")      # only the generated rows are returned (model.py:1118)
             self.last_intermediates = inter
-            return [(images[k].permute(1, 2, 0).detach().cpu().numpy() * 255).astype(np.uint8) for k in range(K)]
+            return images_to_u8(images)
         finally:
             self.controller = single
             self.unet.controller = single
@@ -1172,7 +1180,7 @@ class FreeFinePipeline:
                 c.reset()
             images = self.latent2image(latents[:, 0].contiguous(), return_type="pt")
             self.last_intermediates = inter
-            return [(images[k].permute(1, 2, 0).detach().cpu().numpy() * 255).astype(np.uint8) for k in range(K)]
+            return images_to_u8(images)
         finally:
             self.controller = single
             self.unet.controller = single
