@@ -162,3 +162,19 @@ def test_monocular_depth_wrapper_around_a_depth_network():
     assert min(seen["shape"][2:]) in (518 // 14 * 14, 518) and d.shape == (60, 90) and d.dtype == np.float32
     assert (np.diff(d.mean(0)) <= 1e-4).all()                   # depth = max - disparity: falls to the right
     assert d.min() > 0 and abs(d.min() - 0.1 * (d.max() - d.min()) / 1.0) < 0.02      # pushed back by translate_factor * max(depth before the push)
+
+
+def test_images_to_u8_matches_the_reference_expression():
+    """pipeline.images_to_u8 (multiply and truncating cast on the tensor's device, one contiguous copy) returns the bytes of the reference's
+    `(x.permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8)` (/root/reference/src/demo/model.py:1046-1049) -- incl. the exact ends of the range"""
+    import numpy as np
+    import torch
+    from freefine_amd.pipeline import images_to_u8
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(3, 3, 16, 24, generator=g)
+    x[0, 0, 0, :6] = torch.tensor([0.0, 1.0, 0.999999, 1 / 255, 254.9999 / 255, 0.5])
+    got = images_to_u8(x)
+    assert len(got) == 3 and got[0].shape == (16, 24, 3) and got[0].dtype == np.uint8
+    for k in range(3):
+        ref = (x[k].permute(1, 2, 0).numpy() * 255).astype(np.uint8)
+        assert (got[k] == ref).all()
