@@ -258,7 +258,8 @@ def parity_leg(args, device, model):
                      "compose 15: reference-generated, f32 + bf16x3), ::test_full_size_n50_schedules_vs_oracle_fixture (SD-2.1 topology 64x64, N=50, "
                      "start_step 35 and 0, N=20: oracle-generated, f32 + bf16x3) and ::test_full_size_n50_other_hooks_vs_oracle_fixture (the same topology "
                      "under the bg-gen hook at start_step 1 and the compose hook with R = 2 references at start_step 15), absolute latent L-inf <= 1e-3 at "
-                     "every step; profiles/r5_planted_gain_sensitivity.txt: the headline mode's deviation over this schedule at planted gains 0 / 0.5 / 1 / 3 "
+                     "every step; ::test_full_size_bench_layout_24_edits_per_batch_vs_oracle_fixture (this layout itself: 24 edits per UNet batch, split-bf16, "
+                     "N=50 start_step 0, image 0 against the oracle fixture); profiles/r5_planted_gain_sensitivity.txt: the headline mode's deviation over this schedule at planted gains 0 / 0.5 / 1 / 3 "
                      "(2-3e-5 of |latent| max at every gain; bf16: 1-2.5e-2)")}
     rec, m32 = timed_mode(args, device, "f32", max(1, args.extra_steps // 3))      # (0.4-0.5 images/s: one timed step of the headline's batch layout)
     _F32_TRAJ = ref = one_image_trajectory(m32, args)

@@ -618,6 +618,51 @@ def test_full_size_n50_schedules_vs_oracle_fixture(gpu, case):
         torch.cuda.empty_cache()
 
 
+def test_full_size_bench_layout_24_edits_per_batch_vs_oracle_fixture(gpu):
+    """bench.py's DEFAULT layout itself against the oracle: 24 independent edits in one image-major UNet batch (48 rows in the inversion pass, 72 physical
+    rows in the guided pass: row de-duplication, reference-stream reuse, hipGraphs, attention in row ranges of 16), split-bf16 mode, full-size SD-2.1
+    topology, the metric's schedule (N = 50, start_step = 0: 50 + 50 forwards, planted denoiser path).  Image 0 of the batch is the fs_edit_s0 fixture's
+    case (tests/golden/g10_fullsize_fs_edit_s0.npz, generated by OraclePipeline in the build container); the other 23 have their own images, masks and
+    seeds.  Gate: ABSOLUTE latent L-inf <= 1e-3 at every step for image 0 (edited and reference row), every other image finite with its own result."""
+    from golden_cases import fullsize_cases, fullsize_inputs
+    from freefine_amd.config import UNetConfig
+    from freefine_amd.weights import plant_denoiser_path
+    from oracle import sd_unet
+    g = np.load(os.path.join(GOLD, "g10_fullsize_fs_edit_s0.npz"))
+    ori_img, coarse, ori, tgt, draw, cons_sup = fullsize_inputs()
+    planted, kw = fullsize_cases()["fs_edit_s0"]
+    kw = dict(kw)
+    text, gs, eta = kw.pop("guidance_text"), kw.pop("guidance_scale"), kw.pop("eta")
+    kw = {k: kw[k] for k in ("end_step", "num_step", "start_step", "method_type", "end_scale")}
+    ust = plant_denoiser_path(sd_unet.init_unet(sd_unet.unet_config("sd21-base"), seed=0).state_dict(), UNetConfig.preset("sd21-base"), planted)
+    K = 24
+    cases, seeds = [], []
+    for i in range(K):
+        dy, dx = 8 * (i % 5), 8 * (i // 5)                         # image i: the fixture's inputs moved by (dy, dx) (images rolled, masks shifted: they stay inside)
+        sh = lambda a: np.roll(np.roll(a, dy, 0), dx, 1)
+        cases.append(dict(ori_img=sh(ori_img), ori_mask=sh(ori), coarse_input=sh(coarse), target_mask=sh(tgt), guidance_text=text if i % 3 else text + " " * (i > 0),
+                          draw_mask=sh(draw)))
+        seeds.append(42 + 17 * i)
+    model = make_pipe(gpu, "sd21-base", "edit", graph=True, ustate=ust, x3=True)
+    imgs = model.FreeFine_generation_batch(cases, gs, eta, seeds=seeds, return_intermediates=True, verbose=False, **kw)
+    assert len(imgs) == K and all(im.shape == (512, 512, 3) and im.dtype == np.uint8 for im in imgs)
+    traj = torch.stack([t.detach().float().cpu() for t in model.last_intermediates[0]])
+    ref_e, ref_r = g["traj_edit"], g["traj_ref"]
+    assert traj.shape[0] == ref_e.shape[0] == kw["num_step"] - kw["start_step"] + 1
+    d_e = (traj[:, 0] - torch.from_numpy(ref_e)).abs().flatten(1).max(1).values
+    d_r = (traj[::5, 1] - torch.from_numpy(ref_r)).abs().flatten(1).max(1).values
+    print(f"24 edits per UNet batch, split-bf16, N=50 start_step=0: image 0 ABSOLUTE latent L-inf vs oracle fixture: edited row max {d_e.max():.2e} (final {d_e[-1]:.2e}), "
+          f"reference row {d_r.max():.2e}; image max |diff| {np.abs(imgs[0][::4, ::4].astype(int) - g['img'].astype(int)).max()}")
+    assert d_e.max() < TOL and d_r.max() < TOL
+    assert np.abs(imgs[0][::4, ::4].astype(int) - g["img"].astype(int)).max() <= 1
+    finals = torch.stack([model.last_intermediates[j][-1].detach().float().cpu() for j in range(K)])
+    assert torch.isfinite(finals).all()
+    for j in range(1, K):                                          # every image got its own result (no row of image 0 leaked into another slot)
+        assert (finals[j] - finals[0]).abs().max() > 1e-3, j
+    del model
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("case", ["fs_bg_s1", "fs_cmp_s15"])
 def test_full_size_n50_other_hooks_vs_oracle_fixture(gpu, case):
     """The other two hooks at FULL size on the metric's N = 50 schedules (round 5; G10 covered the edit hook only): background generation at
