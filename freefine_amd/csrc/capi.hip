@@ -1098,6 +1098,12 @@ static int launch_xattn_x3(hipStream_t s, const ffn_attn_desc& d, int nkf) {
     return nw == 8 ? launch_xattn_x3_nw<8>(s, d, nkf, 8) : launch_xattn_x3_nw<4>(s, d, nkf, 8);
 }
 static bool xattn_x3_fits(const ffn_attn_desc& d, int nkf) { return d.npass * 2 * (nkf * 2 + 4 * ((nkf + 1) / 2)) * 1024 <= 160 * 1024; }
+// attn_x3w_kernel lives in its own translation unit (attn_x3w.hip: different code generation flags)
+extern "C" __attribute__((visibility("hidden"))) int fx3w_launch(hipStream_t s, const ffn_attn_desc* d, int masks);
+static bool attn_x3w_on() {       // FFN_ATTN_X3W=0: attn_x3p_kernel<., PAIRKV> (round 5) instead; read per call so that tests can compare the two
+    const char* e = getenv("FFN_ATTN_X3W");
+    return !e || atoi(e) != 0;
+}
 static bool attn_has_masks(const ffn_attn_desc& d) {
     for (int pi = 0; pi < d.npass; ++pi)
         for (int b = 0; b < d.Bo; ++b) {
@@ -1128,7 +1134,8 @@ extern "C" int ffn_attn_kernel_name(int dtype, const ffn_attn_desc* d, char* buf
         }
         bool masks, pp;
         attn_bf16_choice(*d, &masks, &pp);
-        if (pp) snprintf(buf, len, "void attn_x3p_kernel<%s, %s>(ffn_attn_desc)", attn_has_masks(*d) ? "true" : "false", d->kv_pair ? "true" : "false");
+        if (pp && d->kv_pair && attn_x3w_on()) snprintf(buf, len, "void attn_x3w_kernel<%s>(ffn_attn_desc)", attn_has_masks(*d) ? "true" : "false");
+        else if (pp) snprintf(buf, len, "void attn_x3p_kernel<%s, %s>(ffn_attn_desc)", attn_has_masks(*d) ? "true" : "false", d->kv_pair ? "true" : "false");
         else snprintf(buf, len, "void attn_x3_kernel<%s>(ffn_attn_desc)", attn_has_masks(*d) ? "true" : "false");
         return FFN_OK;
     }
@@ -1184,6 +1191,11 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
         attn_bf16_choice(*d, &masks_pp, &pp);      // the ping-pong schedule has the same preconditions as attn_pp_kernel's (d = 64, Sk % 64 == 0, S >= 128, ...)
         if (pp) {
             constexpr int lds = 5 * (2 * 8192) + 8 * 4 * 2 * 64 * 16;      // K ring of 2 + V^T ring of 3 [hi | lo] images, multi-pass sums
+            if (d->kv_pair && attn_x3w_on()) {      // round 6: one wave per SIMD on 32x32x16 MFMAs (attention_x3w.h), same pre-split images
+                const hipError_t e = (hipError_t)fx3w_launch(s, d, attn_has_masks(*d) ? 1 : 0);
+                if (e != hipSuccess) return fail(FFN_EHIP, "attn(split-bf16, one wave per SIMD): %s", hipGetErrorString(e));
+                return FFN_OK;
+            }
             if (d->kv_pair) {                       // pre-split K / V^T images by LDS-DMA (+ 512 B of key-mask bytes)
                 constexpr int ldsp = lds + 512;
                 if (attn_has_masks(*d)) {

@@ -534,8 +534,9 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
         descs.append((b0, nb, d))
     # split-bf16 self attention on the ping-pong kernel: K / V^T are split ONCE per call into the bf16 images the kernel stages by LDS-DMA
     # (ffn_attn_presplit; the kernel's 16 query-block workgroups per (row, head) otherwise each split the whole K / V^T in their key loops)
+    # (the images are addressed with 32-bit byte offsets: K / V^T beyond 2 GiB keep the in-kernel split instead of failing in ffn_attn)
     if dcode == L.FFN_BF16X3 and _ATTN_PRESPLIT and Dh == 64 and Sk % 64 == 0 and S >= 128 and k.stride(2) == 1 and vt.stride(2) == 1 \
-            and k.stride(0) == Sk * k.stride(1) and vt.stride(0) == heads * Dh * vt.stride(1):
+            and k.stride(0) == Sk * k.stride(1) and vt.stride(0) == heads * Dh * vt.stride(1) and k.shape[0] * Sk * heads * 256 < 2 ** 31 - 65536:
         nbuf = CT.create_string_buffer(160)
         names = []
         for _, _, d in descs:

@@ -176,8 +176,9 @@ typedef struct ffn_attn_desc {
     int npass;
     int out_pair;       /* FFN_BF16X3 with D <= 64 only: out is the bf16 PAIR form [Bo][S][ldo] of rows of ldo/2 columns (layout: FFN_BF16X3 above), the A operand of
                            the to_out projection's FFN_BF16X3 GEMM; 0 = fp32 rows */
-    int kv_pair;        /* FFN_BF16X3 launches that run attn_x3p_kernel (ffn_attn_kernel_name says so) only: k / vt are the PRE-SPLIT bf16 images
-                           ffn_attn_presplit wrote (ldk / ldvt ignored); 0 = fp32 k / vt */
+    int kv_pair;        /* FFN_BF16X3 launches that run attn_x3p_kernel (ffn_attn_kernel_name with kv_pair = 0 says so) only: k / vt are the PRE-SPLIT bf16
+                           images ffn_attn_presplit wrote (ldk / ldvt ignored; the launch then runs attn_x3w_kernel, attention_x3w.h -- round 6: one wave
+                           per SIMD on 32x32x16 MFMAs -- or, with FFN_ATTN_X3W=0 in the environment, attn_x3p_kernel<., PAIRKV>); 0 = fp32 k / vt */
     ffn_attn_entry e[FFN_ATT_MAXP * FFN_ATT_MAXB]; /* entry (p,b) at p*FFN_ATT_MAXB + b */
 } ffn_attn_desc;
 int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d);
