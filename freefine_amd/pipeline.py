@@ -93,6 +93,13 @@ class FreeFinePipeline:
         memory (freefine_amd.dist.broadcast_state; bf16 payload for the matrices in fast mode), so ALL ranks must call it with the same
         arguments ("auto": only when a process group with more than one rank is initialised).  The default (False) is the reference's
         behaviour: every caller reads the checkpoint itself (freefine_batch_infer_2d.py:149), safe on a subset of ranks."""
+        ucfg, ust, vcfg, vst, tok, enc, sched, dtype = cls.components(path, torch_dtype, device, seed, broadcast)
+        return cls.from_state(ucfg, ust, vcfg, vst, tok, enc, sched, dtype, device, x3=x3, fp8_conv=fp8_conv)
+
+    @classmethod
+    def components(cls, path, torch_dtype=torch.float32, device="cuda:0", seed=0, broadcast=False):
+        """what `from_pretrained` hands to `from_state`: configs, host (or, after a broadcast, device-resident) parameter states, tokenizer, text
+        encoder, scheduler, storage dtype -- without building the executors, so the whole loading / broadcasting path runs without a GPU."""
         from . import dist as FD
         dtype = torch.float32 if torch_dtype == torch.float32 else torch.bfloat16
         shared = FD.active() if broadcast == "auto" else bool(broadcast)
@@ -108,27 +115,7 @@ class FreeFinePipeline:
             tok, enc = ByteTokenizer(), SyntheticTextEncoder(ucfg.cross_attention_dim)
             sched = DDIMScheduler()
         else:
-            import json
-            ucd = vcd = None
-            sc = {}
-            if lead:
-                ucd, ust = load_safetensors_dir(path, "unet")
-                vcd, vst = load_safetensors_dir(path, "vae")
-                sp = os.path.join(path, "scheduler", "scheduler_config.json")
-                if os.path.exists(sp):
-                    with open(sp) as f:
-                        sc = {k: v for k, v in json.load(f).items() if k in ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule",
-                                                                              "steps_offset", "set_alpha_to_one", "prediction_type")}
-            if shared:
-                ucd, vcd, sc = FD.broadcast_object((ucd, vcd, sc))
-            ucfg = UNetConfig.from_diffusers(ucd)
-            vcfg = VAEConfig(block_out_channels=tuple(vcd["block_out_channels"]), layers_per_block=vcd["layers_per_block"],
-                             latent_channels=vcd["latent_channels"], norm_num_groups=vcd.get("norm_num_groups", 32),
-                             scaling_factor=0.18215)
-            sched = DDIMScheduler(**sc)
-            from transformers import CLIPTextModel, CLIPTokenizer
-            tok = CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer"))
-            enc = CLIPTextModel.from_pretrained(os.path.join(path, "text_encoder")).eval()
+            ucfg, ust, vcfg, vst, tok, enc, sched = cls.load_folder(path, shared=shared, lead=lead)
         if shared:
             if lead:        # the shape tables are defined on normalised names: rename legacy VAE keys before the names travel
                 ust, vst = normalize_state_dict(ust), normalize_state_dict(vst)
@@ -137,7 +124,66 @@ class FreeFinePipeline:
             mdt = torch.float32 if dtype == torch.float32 else torch.bfloat16
             ust = FD.broadcast_state(ust, unet_param_shapes(ucfg), device, matrix_dtype=mdt)
             vst = FD.broadcast_state(vst, vae_param_shapes(vcfg), device, matrix_dtype=mdt)
-        return cls.from_state(ucfg, ust, vcfg, vst, tok, enc, sched, dtype, device, x3=x3, fp8_conv=fp8_conv)
+        return ucfg, ust, vcfg, vst, tok, enc, sched, dtype
+
+    @staticmethod
+    def read_scheduler_config(path):
+        """scheduler/scheduler_config.json of a HF-layout SD folder -> DDIMScheduler kwargs, the way `DDIMScheduler.from_config(model.scheduler.config)`
+        consumes SD's PNDM config (/root/reference/evaluation/FreeFine/freefine_batch_infer_2d.py:151, src/demo/model.py:123-127, 384).  The hot path's
+        scheduler arithmetic HARD-CODES what these constants mean (epsilon prediction in inv_step / ctrl_step, "leading" timestep spacing with the
+        offset, alpha_bar_0 as the final alpha), so nothing is defaulted silently: a missing file or key, a v-prediction checkpoint (SD-2.1 768-v),
+        trained betas or another spacing raise here instead of producing a wrong trajectory."""
+        import json
+        sp = os.path.join(path, "scheduler", "scheduler_config.json")
+        if not os.path.exists(sp):
+            raise FileNotFoundError(f"{sp} not found: the DDIM constants (betas, steps_offset, set_alpha_to_one, prediction_type) are read from the "
+                                    "checkpoint, never assumed")
+        with open(sp) as f:
+            cfg = json.load(f)
+        need = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "steps_offset", "set_alpha_to_one")
+        missing = [k for k in need if k not in cfg]
+        if missing:
+            raise ValueError(f"{sp}: missing {missing}")
+        if cfg.get("prediction_type", "epsilon") != "epsilon":
+            raise ValueError(f"{sp}: prediction_type={cfg['prediction_type']!r}; FreeFine's inv_step / ctrl_step assume epsilon prediction "
+                             "(stable-diffusion-2-1-base, not the 768-v model)")
+        if cfg.get("trained_betas") is not None:
+            raise ValueError(f"{sp}: trained_betas is set; only the scaled_linear / linear schedules are implemented")
+        if cfg["beta_schedule"] not in ("scaled_linear", "linear"):
+            raise ValueError(f"{sp}: beta_schedule={cfg['beta_schedule']!r} not implemented")
+        if cfg.get("timestep_spacing", "leading") != "leading":
+            raise ValueError(f"{sp}: timestep_spacing={cfg['timestep_spacing']!r}; the reference's loops run on leading spacing")
+        out = {k: cfg[k] for k in need}
+        out["prediction_type"] = "epsilon"
+        return out
+
+    @classmethod
+    def load_folder(cls, path, shared=False, lead=True):
+        """Everything `from_pretrained` reads from a HF-layout Stable-Diffusion folder, on the host: (UNetConfig, unet state, VAEConfig, vae state,
+        tokenizer, text encoder, DDIMScheduler).  States are fp32 (fp16 / bf16 shards are up-cast), under current diffusers parameter names (the hub's
+        legacy VAE attention names are renamed); with `shared` only the lead rank reads the tensors (the others get None) and the configs travel by
+        broadcast_object.  Split out so that the loading path is testable without a GPU (tests/test_checkpoint_cpu.py)."""
+        from . import dist as FD
+        ucd = vcd = sc = ust = vst = None
+        if lead:
+            ucd, ust = load_safetensors_dir(path, "unet")
+            vcd, vst = load_safetensors_dir(path, "vae")
+            sc = cls.read_scheduler_config(path)
+        if shared:
+            ucd, vcd, sc = FD.broadcast_object((ucd, vcd, sc))
+        ucfg = UNetConfig.from_diffusers(ucd)
+        vcfg = VAEConfig(block_out_channels=tuple(vcd["block_out_channels"]), layers_per_block=vcd["layers_per_block"],
+                         latent_channels=vcd["latent_channels"], norm_num_groups=vcd.get("norm_num_groups", 32),
+                         scaling_factor=vcd.get("scaling_factor", 0.18215))
+        if abs(vcfg.scaling_factor - 0.18215) > 1e-12:
+            raise ValueError(f"vae scaling_factor {vcfg.scaling_factor}: the reference multiplies latents by the literal 0.18215 (src/demo/model.py:267-272)")
+        sched = DDIMScheduler(**sc)
+        from transformers import CLIPTextModel, CLIPTokenizer
+        tok = CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer"))
+        enc = CLIPTextModel.from_pretrained(os.path.join(path, "text_encoder")).eval()
+        if enc.config.hidden_size != ucfg.cross_attention_dim:
+            raise ValueError(f"text encoder width {enc.config.hidden_size} != unet cross_attention_dim {ucfg.cross_attention_dim}")
+        return ucfg, ust, vcfg, vst, tok, enc, sched
 
     @classmethod
     def from_state(cls, ucfg, ustate, vcfg, vstate, tokenizer, text_encoder, scheduler=None, dtype=torch.float32, device="cuda:0", x3=False,
@@ -278,10 +324,10 @@ class FreeFinePipeline:
         prompts = list(prompts)
         cache = self._text_cache if self.text_cache else None
         missing = [q for q in dict.fromkeys(prompts) if cache is None or q not in cache]
-        # the hits are taken out of the cache BEFORE anything is inserted or evicted (an eviction made room for this call's misses could
-        # otherwise remove a prompt of this very call that was counted as a hit) and re-inserted behind the misses: most recently used last
-        fresh = {q: cache.pop(q) for q in dict.fromkeys(prompts) if cache is not None and q in cache}
-        hits = list(fresh)
+        # the hits are READ here and moved behind the misses only in the final update (an eviction made room for this call's misses must not
+        # remove a prompt of this very call that was counted as a hit; and an encoder failure below leaves the cache as it was)
+        hits = [q for q in dict.fromkeys(prompts) if cache is not None and q in cache]
+        fresh = {q: cache[q] for q in hits}
         if missing:
             enc = self.text_encoder
             if isinstance(enc, torch.nn.Module) and not self._text_on_device:
@@ -301,7 +347,9 @@ class FreeFinePipeline:
             for j, q in enumerate(missing):
                 fresh[q] = out[j]
         if cache is not None:
-            for q in missing + hits:
+            for q in hits:
+                cache.pop(q)
+            for q in missing + hits:                            # most recently used last
                 cache[q] = fresh[q]
             while len(cache) > self.text_cache_max:
                 cache.pop(next(iter(cache)))

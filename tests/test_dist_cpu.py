@@ -106,3 +106,50 @@ def test_bench_gpus_flag_launches_ranks(monkeypatch):
     assert "--nproc-per-node=4" in calls[0][0] and calls[0][1]["PATH"] == "x"
     assert bench.maybe_launch_ranks(ns, ["--gpus", "4"], environ={"WORLD_SIZE": "4", "RANK": "1"}) is None and len(calls) == 1
     assert bench.maybe_launch_ranks(argparse.Namespace(gpus=1), [], environ={}) is None and len(calls) == 1
+
+
+FOLDER_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["FF_ROOT"]); sys.path.insert(0, os.path.join(os.environ["FF_ROOT"], "tools"))
+from freefine_amd.pipeline import FreeFinePipeline
+from freefine_amd.weights import synthetic_state, unet_param_shapes, vae_param_shapes
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+folder = os.environ["FF_FOLDER"]
+# rank 1 must NOT read the tensors: hide them from it (configs / tokenizer / text encoder are small files every rank reads itself)
+if rank == 1:
+    import freefine_amd.pipeline as P
+    real = P.load_safetensors_dir
+    def guard(*a, **k):
+        raise AssertionError("a non-lead rank read the checkpoint tensors")
+    P.load_safetensors_dir = guard
+ucfg, ust, vcfg, vst, tok, enc, sched, dtype = FreeFinePipeline.components(folder, torch.float32, "cpu", broadcast="auto")
+ref_u = synthetic_state(unet_param_shapes(ucfg), 9)
+ref_v = synthetic_state(vae_param_shapes(vcfg), 10)
+assert ucfg.heads == (2, 4, 4, 4) and sched.config.steps_offset == 1
+assert set(ust) == set(ref_u) and all(torch.equal(ust[k], ref_u[k]) for k in ref_u), "unet bits differ on rank %d" % rank
+assert set(vst) == set(ref_v) and all(torch.equal(vst[k].reshape(ref_v[k].shape), ref_v[k]) for k in ref_v), "vae bits differ on rank %d" % rank
+# fast mode: the matrices travel as bf16 (what the packers round them to anyway), 1-D parameters as fp32
+_, u16, *_ = FreeFinePipeline.components(folder, torch.bfloat16, "cpu", broadcast="auto")
+k = "conv_in.weight"
+assert u16[k].dtype == torch.bfloat16 and torch.equal(u16[k], ref_u[k].to(torch.bfloat16)) and u16["conv_in.bias"].dtype == torch.float32
+if rank == 0:
+    print("FOLDER_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_world2_gloo_checkpoint_folder_broadcast(tmp_path):
+    """from_pretrained(<HF folder>, broadcast="auto") under a 2-rank process group: rank 0 reads the safetensors, rank 1 receives the same bits
+    (fp32) / the same bf16 roundings (fast mode) without touching the tensor files; configs and scheduler constants agree on both."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_synthetic_checkpoint as M
+    folder = str(tmp_path / "sd_tiny")
+    M.write(folder, "tiny", "tiny", "fp32", seed=9)
+    script = tmp_path / "worker_folder.py"
+    script.write_text(FOLDER_WORKER)
+    env = dict(os.environ, FF_ROOT=ROOT, FF_FOLDER=folder)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29519", str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "FOLDER_OK" in out.stdout

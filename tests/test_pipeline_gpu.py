@@ -4,6 +4,7 @@
 for the edit, background-generation and composition loops.  Tolerance: latent L-inf <= 1e-3 (north-star tolerance);
 measured deviations are ~1e-5.  A bf16 fast-mode run is bounded loosely and its deviation printed."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -13,6 +14,7 @@ from golden_cases import BG_CASES, CMP_CASES, compose_masks, edit_cases, mask_in
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 torch.set_grad_enabled(False)
 TOL = 1e-3
 
@@ -700,3 +702,66 @@ def test_full_size_n50_other_hooks_vs_oracle_fixture(gpu, case):
             assert np.abs(img[::4, ::4].astype(int) - g["img"].astype(int)).max() <= 1
         del model
         torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 6: the checkpoint-folder branch of from_pretrained (tools/make_synthetic_checkpoint.py writes the HF layout offline)
+# ---------------------------------------------------------------------------------------------------------------------
+def _hook_edit(model):
+    from freefine_amd.attention import Attention_Modulator, register_attention_control
+    from freefine_amd.scheduler import DDIMScheduler
+    model.scheduler = DDIMScheduler.from_config(model.scheduler.config)
+    model.controller = Attention_Modulator(start_layer=10)
+    register_attention_control(model, model.controller)
+    model.modify_unet_forward()
+    return model
+
+
+@pytest.mark.parametrize("fdtype", ["fp32", "fp16"])
+def test_from_pretrained_folder_equals_from_state_bit_for_bit(gpu, tmp_path, fdtype):
+    """FreeFinePipeline.from_pretrained(<HF-layout folder>) -- the first line of every reference call site (freefine_batch_infer_2d.py:148-157) --
+    against from_state on the tensors the folder was written from (fp16 file: on their fp16 roundings): one small edit through both pipelines,
+    same transformers tokenizer / text encoder objects' weights, latent trajectory and image BIT FOR BIT equal.  Covers config.json parsing,
+    safetensors loading + up-cast, legacy VAE attention names, scheduler_config.json and the CLIP wiring on the device."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_synthetic_checkpoint as M
+    from transformers import CLIPTextModel, CLIPTokenizer
+    from freefine_amd.pipeline import FreeFinePipeline
+    d = str(tmp_path / "sd_tiny")
+    ucfg, vcfg, ust, vst = M.write(d, "tiny", "tiny", fdtype, seed=5)
+    a = _hook_edit(FreeFinePipeline.from_pretrained(d, torch_dtype=torch.float32, device=gpu).to(gpu))
+    if fdtype == "fp16":
+        ust, vst = ({k: v.to(torch.float16).float() for k, v in st.items()} for st in (ust, vst))
+    tok = CLIPTokenizer.from_pretrained(os.path.join(d, "tokenizer"))
+    enc = CLIPTextModel.from_pretrained(os.path.join(d, "text_encoder")).eval()
+    b = _hook_edit(FreeFinePipeline.from_state(ucfg, ust, vcfg, vst, tok, enc, None, torch.float32, gpu))
+    assert a.scheduler.config.steps_offset == 1 and a.scheduler.config.set_alpha_to_one is False
+    ori_img, coarse, _ = synth_images()
+    ori, tgt, *_ = mask_inputs()
+    kw = dict(end_step=6, num_step=6, start_step=2, seed=42, end_scale=0.0, return_intermediates=True, verbose=False)
+    ia = a.FreeFine_generation(ori_img, ori, coarse, tgt, "a photo of a cup", 7.5, 1.0, **kw)
+    ib = b.FreeFine_generation(ori_img, ori, coarse, tgt, "a photo of a cup", 7.5, 1.0, **kw)
+    assert len(a.last_intermediates) == len(b.last_intermediates) > 0
+    for x, y in zip(a.last_intermediates, b.last_intermediates):
+        assert torch.equal(x, y)
+    assert np.array_equal(ia, ib) and np.isfinite(ia.astype(float)).all()
+    assert a.text_encoder_calls > 0 and isinstance(a.text_encoder, torch.nn.Module)
+
+
+def test_geobench_driver_runs_from_a_checkpoint_folder(gpu, tmp_path):
+    """`python evaluation/FreeFine/freefine_batch_infer_2d.py --base-dir <GeoBenchMeta> --model <SD folder>`: the reference's own command line with a
+    folder (synthetic weights, tiny topology) on the synthetic GeoBench tree -- the driver process builds its pipeline through from_pretrained."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_synthetic_checkpoint as M
+    from freefine_amd import geobench
+    d = str(tmp_path / "sd_tiny")
+    M.write(d, "tiny", "tiny", "fp32", seed=1)
+    root = str(tmp_path / "geo")
+    geobench.make_synthetic_dataset(root, n_images=1, edits_per_image=2, size=128, seed=3, with_backgrounds=True)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "evaluation", "FreeFine", "freefine_batch_infer_2d.py"), "--base-dir", root, "--model", d,
+                          "--dtype", "f32", "--batch", "2"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert os.path.exists(os.path.join(root, "generated_results_freefine_2d.json"))
+    pngs = [f for _, _, fs in os.walk(os.path.join(root, geobench.GEN_SUBDIR)) for f in fs if f.endswith(".png")]
+    assert len(pngs) >= 2, pngs
