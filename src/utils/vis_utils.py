@@ -4,9 +4,12 @@ box) on PIL / numpy / scipy.
 
 Each function restates the documented behaviour of the cv2 call the reference makes (cited /root/reference/src/utils/vis_utils.py):
 nearest / Lanczos-4 resize, ones-kernel dilation, getRotationMatrix2D + warpAffine (bilinear for images, nearest for masks,
-constant-0 border), BGR<->RGB PNG I/O.  PARITY UNPINNED for the interpolating calls: cv2 cannot be imported in this
-environment, so no golden vectors exist; cv2's 8-bit paths use fixed-point coefficient tables, against which these float
-restatements may differ by 1 LSB.  Index-exact functions (nearest resize, dilation, mask arithmetic incl. the uint8 wrap of
+constant-0 border), BGR<->RGB PNG I/O.  PINNED ON ONE REFERENCE VECTOR since round 6: the reference tree holds one input -> output set of
+its own coarse edit (Examples/Editing/2D/tower), and re_edit_2d + the nearest mask resize reproduce its target mask exactly over the full
+frame and its coarse image exactly inside it (tests/golden/g12_tower_coarse_edit.npz, tools/pin_n2_tower.py) -- that example is an integer
+translation, so the INTERPOLATING paths (bilinear weights under rotation / scaling, Lanczos-4) remain PARITY UNPINNED: cv2 cannot be
+imported in this environment, and its 8-bit paths use fixed-point coefficient tables, against which these float restatements may differ
+by 1 LSB.  Index-exact functions (nearest resize, dilation, mask arithmetic incl. the uint8 wrap of
 get_constrain_areas, JSON / path helpers) are covered by tests/test_vis_utils_cpu.py.
 """
 import json

@@ -178,3 +178,34 @@ def test_images_to_u8_matches_the_reference_expression():
     for k in range(3):
         ref = (x[k].permute(1, 2, 0).numpy() * 255).astype(np.uint8)
         assert (got[k] == ref).all()
+
+
+def test_re_edit_2d_reproduces_the_references_tower_example():
+    """N2 pinned on the one input -> output set the reference tree holds (/root/reference/Examples/Editing/2D/tower: source, source_mask, target_mask,
+    coarse_result of the reference's own coarse 2-D edit; fixture written by tools/pin_n2_tower.py, which recovers edit_param = (-50, -50, 0, 1, 1)
+    as the UNIQUE parameter set that maps one mask onto the other).  Pins: the cv2.INTER_NEAREST rule of read_and_resize_mask on the 640 x 640
+    source mask (PIL's nearest rule misses by 437 pixels), getRotationMatrix2D / the translation conventions, the nearest mask warp, the
+    paste-over-background composition -- target mask EXACT over the full frame, coarse image EXACT inside it (an integer translation: the bilinear
+    weights degenerate, so rotation / scaling stay parity-unpinned and say so in src/utils/vis_utils.py)."""
+    from src.utils import vis_utils as V
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g12_tower_coarse_edit.npz"))
+    sm640 = np.unpackbits(g["source_mask_640"]).reshape(640, 640).astype(np.uint8) * 255
+    tm = np.unpackbits(g["target_mask_512"]).reshape(512, 512).astype(np.uint8) * 255
+    param = tuple(g["edit_param"].tolist())
+    assert param == (-50.0, -50.0, 0.0, 1.0, 1.0)
+    sm = V._resize_nearest(sm640, (512, 512))
+    sm[sm > 0] = 1                                                           # read_and_resize_mask's binarisation
+    zero = np.zeros((512, 512, 3), np.uint8)
+    _, tmask, _ = V.re_edit_2d(zero, sm, param, zero)
+    assert tmask.dtype == np.uint8 and np.array_equal(tmask, tm)             # exact, full frame (89706 object pixels, clipped at the top edge)
+    x0, x1 = (int(v) for v in g["crop"])
+    src_c, co_c = g["source_crop"], g["coarse_crop"]
+    bg = np.full_like(src_c, 7)                                              # the inpainted background is not part of the fixture: a sentinel
+    final, tmask_c, hole = V.re_edit_2d(src_c, sm[:, x0:x1], param, bg)
+    band = np.zeros((512, x1 - x0), bool)
+    band[:, :x1 - x0 - 50] = True                                            # columns whose source pixel (x + 50) lies inside the crop
+    inside = (tm[:, x0:x1] > 0) & band
+    assert inside.sum() > 25000 and np.array_equal(tmask_c[band] > 0, tm[:, x0:x1][band] > 0)
+    assert np.array_equal(final[inside], co_c[inside])                       # the moved object, bit for bit
+    assert (final[~(tmask_c > 0)] == 7).all()                                # everything else is the background handed in
+    assert (hole[(sm[:, x0:x1] > 0) & ~(tmask_c > 0)] == 0).all()            # the vacated region of the hole image
