@@ -875,7 +875,9 @@ static ffn_igemm_desc f8_view(const ffn_igemm_desc& d) {
 extern "C" int ffn_split_pair(void* stream, const float* src, void* dst, long rows, int C, int ld_src) {
     REQUIRE(src && dst && rows > 0 && C > 0 && C % 4 == 0 && ld_src >= C && ld_src % 4 == 0, "split_pair: bad arguments (C=%d, ld_src=%d)", C, ld_src);
     REQUIRE(aligned16(src) && aligned16(dst), "split_pair: pointers must be 16-byte aligned");
-    LAUNCH(split_pair_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, (bf16*)dst, rows, C, ld_src);
+    static const int wide = [] { const char* e = getenv("FFN_PAIR8"); return e ? atoi(e) : 1; }();
+    if (wide && C % 8 == 0 && ld_src % 4 == 0) LAUNCH(split_pair8_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, (bf16*)dst, rows, C, ld_src);
+    else LAUNCH(split_pair_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, (bf16*)dst, rows, C, ld_src);
     return check_launch("split_pair");
 }
 extern "C" int ffn_conv3x3_n4(void* stream, int dtype, const void* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cin) {
@@ -963,6 +965,8 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
             const int nout = (d->flags & FFN_IG_GEGLU) ? d->N / 2 : d->N;
             REQUIRE(dtype == FFN_BF16X3 && !d->residual && d->ldo % 16 == 0 && d->ldo / 2 >= nout, "igemm: pair output needs FFN_BF16X3, no residual, ldo %% 16 == 0, ldo/2 >= columns");
             REQUIRE((d->ldo / 2) % 32 != 0 || nout % 32 == 0 || nout == d->ldo / 2, "igemm: blocked pair output (ldo/2 %% 32 == 0) needs whole 32-column blocks");
+            // every producer derives the layout (blocked / planes) from the ROW WIDTH ldo / 2; the ping-pong GEGLU epilogue always writes blocked rows
+            REQUIRE(nout == d->ldo / 2 || (d->ldo / 2) % 32 == 0, "igemm: pair output into a wider row needs ldo/2 %% 32 == 0 (ldo=%d, columns=%d)", d->ldo, nout);
         }
         if (d->flags & FFN_IG_GEGLU) {
             REQUIRE(d->N % 64 == 0, "igemm: GEGLU needs N %% 64 == 0 (N=%d)", d->N);
@@ -1168,7 +1172,11 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
     REQUIRE(d->D % epc == 0, "attn: D=%d must be a multiple of %d", d->D, epc);
     REQUIRE(d->ldq % epc == 0 && d->ldk % epc == 0 && d->ldvt % epc == 0 && d->ldo % 4 == 0, "attn: leading dims must be chunk aligned");
     REQUIRE(d->ldvt >= d->Sk, "attn: ldvt=%d < Sk=%d", d->ldvt, d->Sk);
-    if (d->out_pair) REQUIRE(dtype == FFN_BF16X3 && d->D <= 64 && d->ldo % 16 == 0 && d->ldo / 2 >= d->heads * d->D, "attn: pair output needs FFN_BF16X3, D <= 64, ldo %% 16 == 0");
+    if (d->out_pair) {
+        REQUIRE(dtype == FFN_BF16X3 && d->D <= 64 && d->ldo % 16 == 0 && d->ldo / 2 >= d->heads * d->D, "attn: pair output needs FFN_BF16X3, D <= 64, ldo %% 16 == 0");
+        // the cross-attention kernel places pair columns by heads * D, the others by ldo / 2: the two agree in these cases only
+        REQUIRE(d->ldo / 2 == d->heads * d->D || ((d->ldo / 2) % 32 == 0 && (d->heads * d->D) % 32 == 0), "attn: pair output into a wider row needs 32-column blocks (ldo=%d, heads*D=%d)", d->ldo, d->heads * d->D);
+    }
     if (d->kv_pair) {
         bool m_, pp_;
         attn_bf16_choice(*d, &m_, &pp_);
@@ -1387,6 +1395,13 @@ extern "C" int ffn_gn_apply(void* stream, int dtype, const void* x, void* y, con
     const int grid = grid_for(nch);
     if (silu & FFN_NORM_OUT_PAIR) {
         REQUIRE(dtype == FFN_F32, "gn_apply: pair output needs fp32 input");
+        static const int wide = [] { const char* e = getenv("FFN_PAIR8"); return e ? atoi(e) : 1; }();      // 0: the round-5 kernels (8-byte stores, libm SiLU)
+        if (wide && C % 8 == 0) {
+            const long n8 = (long)B * HW * (C / 8);
+            if (silu & FFN_NORM_SILU) LAUNCH(gn_apply_pair8_kernel<true>, dim3(grid_for(n8)), dim3(256), 0, s, (const float*)x, (bf16*)y, scale, shift, n8, HW, C);
+            else LAUNCH(gn_apply_pair8_kernel<false>, dim3(grid_for(n8)), dim3(256), 0, s, (const float*)x, (bf16*)y, scale, shift, n8, HW, C);
+            return check_launch("gn_apply(pair, 8 wide)");
+        }
         if (silu & FFN_NORM_SILU) LAUNCH((gn_apply_kernel<float, true, true>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, nch, HW, C);
         else LAUNCH((gn_apply_kernel<float, false, true>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, scale, shift, nch, HW, C);
         return check_launch("gn_apply(pair)");

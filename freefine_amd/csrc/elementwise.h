@@ -155,6 +155,28 @@ __global__ __launch_bounds__(256) void split_pair_kernel(const float* __restrict
     }
 }
 
+// the same, 8 elements per thread (C % 8 == 0): 16-byte stores instead of 8-byte ones (round 6)
+__global__ __launch_bounds__(256) void split_pair8_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long rows, int C, int ld_src) {
+    const int cq = C >> 3;
+    const long n = rows * cq;
+    const int lo_off = pair_lo(C);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / cq;
+        const int c = (int)(i - r * cq) << 3;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(src + r * ld_src + c), x1 = *reinterpret_cast<const f32x4*>(src + r * ld_src + c + 4);
+        const float f[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        u32x4 hi, lo;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            hi[w] = pack_bf16x2(f[2 * w], f[2 * w + 1]);
+            lo[w] = pack_bf16x2(f[2 * w] - __uint_as_float(hi[w] << 16), f[2 * w + 1] - __uint_as_float(hi[w] & 0xffff0000u));
+        }
+        bf16* q = dst + r * 2 * C + pair_pos(c, C);
+        *reinterpret_cast<u32x4*>(q) = hi;
+        *reinterpret_cast<u32x4*>(q + lo_off) = lo;
+    }
+}
+
 // image pre/post for the VAE bracket (model.py:1282-1288, 270-280)
 // uint8 HWC [B,HW,3] -> T NHWC [B,HW,CP]: v/127.5 - 1
 template <typename T>

@@ -149,6 +149,45 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// ---- (3p) apply with PAIR output, 8 channels per thread (round 6): two 16-byte loads, two 16-byte stores (hi / lo).  The 4-channel form above
+// stores 8 bytes per lane (measured on gfx950: 8-byte accesses run at 0.54-0.70 of the 16-byte rate) and, for T = float, evaluates SiLU with libm's
+// expf + an IEEE division (~30 instructions per value: the kernel was VALU-bound, 25 % slower per byte than the statistics pass).  The pair form
+// carries 16-17 significant bits, so SiLU is x * rcp(1 + exp2(-x log2 e)) here (v_exp_f32 / v_rcp_f32: ~1 ulp each, 2e-7 relative).
+// C % 8 == 0 (a thread's 8 channels never straddle a 32-column block of the blocked layout).
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_pair8_kernel(const float* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, long n8_total, int HW, int C) {
+    const int cch = C / 8;
+    const int lo_off = pair_lo(C);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8_total; i += (long)gridDim.x * 256) {
+        const long pix = i / cch;
+        const int c = (int)(i - pix * cch) * 8;
+        const int b = (int)(pix / HW);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + pix * C + c), v1 = *reinterpret_cast<const f32x4*>(x + pix * C + c + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + (long)b * C + c), s1 = *reinterpret_cast<const f32x4*>(scale + (long)b * C + c + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + (long)b * C + c), h1 = *reinterpret_cast<const f32x4*>(shift + (long)b * C + c + 4);
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f[e] = v0[e] * s0[e] + h0[e];
+            f[4 + e] = v1[e] * s1[e] + h1[e];
+        }
+        if (SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = silu_fast(f[e]);
+        }
+        u32x4 hi, lo;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            hi[w] = pack_bf16x2(f[2 * w], f[2 * w + 1]);
+            lo[w] = pack_bf16x2(f[2 * w] - __uint_as_float(hi[w] << 16), f[2 * w + 1] - __uint_as_float(hi[w] & 0xffff0000u));
+        }
+        bf16* q = y + pix * 2 * C + pair_pos(c, C);
+        *reinterpret_cast<u32x4*>(q) = hi;
+        *reinterpret_cast<u32x4*>(q + lo_off) = lo;
+    }
+}
+
 // ---- (3b) apply with fp8 output (FFN_FP8 convolutions): y8[pixel][Cp] = e4m3(act(x * scale + shift) * qs), channels C .. Cp-1 = 0.
 // Cp (a multiple of 128) is the padded channel count the fp8 ping-pong conv needs; qs is the power-of-two activation scale.
 template <bool SILU>

@@ -86,6 +86,7 @@ def _igemm_name(lib, dcode, d):
 # ---------------------------------------------------------------------------------------------------------------
 # weight packing (host side, once at load time)
 # ---------------------------------------------------------------------------------------------------------------
+_GN_CHUNK_MB = float(os.environ.get("FFN_GN_CHUNK_MB", "0"))           # GroupNorm row chunks (MiB of input per chunk; 0 = whole batch at once)
 _ATTN_PRESPLIT = os.environ.get("FFN_ATTN_PRESPLIT", "1") != "0"      # split-bf16 self attention: pre-split K / V^T once per call (0: split inside the kernel's key loop)
 
 
@@ -589,8 +590,22 @@ def groupnorm(x, gamma, beta, G, eps, silu=False, out=None, ws=None, pair=False)
     else:
         partial, scale, shift = ws if ws is not None else gn_workspace(B, HW, Cc, x.device)
     fl = (L.NORM_SILU if silu else 0) | (L.NORM_OUT_PAIR if pair else 0)
-    call = lambda: lib.ffn_groupnorm(_stream(), _dt(x), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B, HW, Cc, G, eps,
-                                     fl, _p(partial), _p(scale), _p(shift))
+    # Row chunks (three-launch form only): statistics and apply of a chunk run back to back, so that the apply pass finds the chunk's input in the
+    # 256 MiB Infinity Cache instead of fetching it from HBM a second time (the three-launch form reads x twice: 12 bytes per element moved for 8).
+    nb = B
+    if partial is not None and _GN_CHUNK_MB > 0 and x.is_contiguous() and out.is_contiguous():
+        row_bytes = HW * Cc * x.element_size()
+        nb = max(1, min(B, int(_GN_CHUNK_MB * 2 ** 20) // row_bytes))
+        nb = -(-B // -(-B // nb))                    # equal chunks
+    def call():
+        rc = 0
+        for b0 in range(0, B, nb):
+            n = min(nb, B - b0)
+            rc = lib.ffn_groupnorm(_stream(), _dt(x), x.data_ptr() + b0 * HW * Cc * x.element_size(), out.data_ptr() + b0 * HW * out.shape[-1] * out.element_size(),
+                                   gamma.data_ptr(), beta.data_ptr(), n, HW, Cc, G, eps, fl, _p(partial), _p(scale), _p(shift))
+            if rc:
+                break
+        return rc
     if _PROF is None:
         L.check(call(), "ffn_groupnorm")
     else:       # algorithmic bytes: one read + one write (the three-launch form reads x twice: that shows as a lower GB/s)

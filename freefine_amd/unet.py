@@ -310,11 +310,13 @@ class HipUNet:
         torch's CUDAGraph.replay() holds it -- and a launch of the ~380-node graph keeps the host thread for milliseconds on ROCm 7.2 (measured:
         5.2 ms per replay, profiles/r5_host_profile_batch1.txt), which serialised the host threads of the one-image-per-call layout.  The graphs
         hold no torch RNG state, so the raw launch is the whole of replay().  FFN_GRAPH_RAW=0 keeps torch's replay()."""
-        if _GRAPH_RAW:
+        if _GRAPH_RAW and hasattr(g["graph"], "raw_cuda_graph_exec"):          # (older torch: no raw handle -> torch's replay())
             ex = g.get("exec")
             if ex is None:
                 ex = g["exec"] = int(g["graph"].raw_cuda_graph_exec())
-            L.check(L.load().ffn_graph_launch(CT.c_void_p(torch.cuda.current_stream().cuda_stream), CT.c_void_p(ex)), "ffn_graph_launch")
+            # replay()'s device guard, kept: the graph runs on the device it was captured on, on THAT device's current stream
+            with torch.cuda.device(g.get("device", torch.cuda.current_device())):
+                L.check(L.load().ffn_graph_launch(CT.c_void_p(torch.cuda.current_stream().cuda_stream), CT.c_void_p(ex)), "ffn_graph_launch")
         else:
             g["graph"].replay()
 
@@ -575,7 +577,7 @@ class HipUNet:
             out = self._run(x_static, text_kv)
         rec = ru is not None and ru["mode"] == "record"
         g = dict(graph=graph, x=x_static, out=out, ref_in=ref_in, ref_bufs=ru.get("static_bufs") if ru is not None else None,
-                 boundary=self.last_boundary if rec else None, kv=self.last_kv if rec else None)
+                 boundary=self.last_boundary if rec else None, kv=self.last_kv if rec else None, device=x_static.device.index)
         if ru is not None:
             for k in ("state_run", "static", "static_bufs", "static_ready"):
                 ru.pop(k, None)

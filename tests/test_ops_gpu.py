@@ -756,7 +756,9 @@ def test_x3_split_pair(gpu):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 320, 320), (4096, 1280, 320), (77 * 4, 640, 1024), (4, 1280, 320), (1000, 4, 320), (16384, 320, 1280),
-                                    (130, 200, 72), (196608 // 8, 640, 640), (2500, 1280, 5120)])
+                                    (130, 200, 72), (196608 // 8, 640, 640), (2500, 1280, 5120),
+                                    # K % 64 == 32: the blocked pair layout with an ODD number of 32-deep stages on the ping-pong core
+                                    (1024, 320, 96), (4096, 320, 160), (3000, 640, 224), (512, 256, 32)])
 def test_x3_linear(gpu, M, N, K):
     from freefine_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N)
@@ -821,6 +823,11 @@ def test_x3_geglu_rowbias_transposed_splitk(gpu):
     dict(B=5, H=16, W=16, Cin=192, Cout=640, stride=1, pad=1, up=False),
     dict(B=4, H=64, W=64, Cin=320, Cout=320, stride=1, pad=1, up=False),
     dict(B=3, H=8, W=8, Cin=2560, Cout=1280, stride=1, pad=1, up=False),       # split-K at the coarse level, Cin = concat width
+    # Cin % 64 == 32: one 32-channel block per tap on the chunk-major walk, odd stage counts, enough rows for a ping-pong tile
+    dict(B=4, H=32, W=32, Cin=32, Cout=320, stride=1, pad=1, up=False),
+    dict(B=4, H=32, W=32, Cin=96, Cout=320, stride=1, pad=1, up=False),
+    dict(B=6, H=16, W=16, Cin=160, Cout=320, stride=1, pad=1, up=False),
+    dict(B=4, H=32, W=32, Cin=96, Cout=256, stride=2, pad=1, up=False),
 ])
 def test_x3_conv3x3(gpu, cfg):
     from freefine_amd import ops
@@ -881,6 +888,13 @@ def test_x3_every_configuration_and_determinism(gpu):
             for sk in (0, 12):
                 out = ops.conv3x3(x, ops.pack_conv3x3(w, dt, x3=True), b, B, H, H, Cin, rowbias=rb, residual=r, splitk=sk)
                 assert relerr(out, ref) < X3_TOL, (cfg, "conv", sk)
+            # Cin = 96: 27 stages of 32 (odd), forced split-K on the chunk-major walk
+            Cin2 = 96
+            x2, w2 = rnd((B, H * H, Cin2), dt, gpu, g), rnd((Cout, Cin2, 3, 3), dt, gpu, g, (9 * Cin2) ** -0.5)
+            ref2 = F.conv2d(x2.double().reshape(B, H, H, Cin2).permute(0, 3, 1, 2), w2.double(), b.double(), padding=1).permute(0, 2, 3, 1).reshape(B, H * H, Cout)
+            for sk in (0, 3, 9):
+                out = ops.conv3x3(x2, ops.pack_conv3x3(w2, dt, x3=True), b, B, H, H, Cin2, splitk=sk)
+                assert relerr(out, ref2) < X3_TOL, (cfg, "conv Cin 96", sk)
     finally:
         lib.ffn_igemm_force_config(-1)
     B, H, Cin, Cout = 12, 64, 320, 320
@@ -1253,7 +1267,14 @@ def test_x3_pair_producers_write_the_blocked_layout(gpu):
         for silu in (False, True):
             f = ops.groupnorm(x, ga, be, 32, 1e-5, silu=silu)
             p = ops.groupnorm(x, ga, be, 32, 1e-5, silu=silu, pair=True)
-            assert ops.pair_width(p) == C and torch.equal(p, ops.split_pair(f, C))
+            assert ops.pair_width(p) == C
+            from freefine_amd import _lib as L_
+            if silu and not L_.load().ffn_gn_fused(B, HW, C, 32):
+                # round 6: the 8-wide pair apply evaluates SiLU as x * rcp(1 + exp2(-x log2 e)) (~2e-7 relative) where the fp32 form calls libm:
+                # same layout, values equal to the pair form's own 2^-17 resolution
+                assert relerr(pair_value(p, C), f) < 8e-6
+            else:
+                assert torch.equal(p, ops.split_pair(f, C))
         f, p = ops.layernorm(x, ga, be), ops.layernorm(x, ga, be, pair=True)
         assert ops.pair_width(p) == C and torch.equal(p, ops.split_pair(f, C))
     M, K, Fh = 4096, 320, 1280

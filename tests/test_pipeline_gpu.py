@@ -738,9 +738,12 @@ def test_from_pretrained_folder_equals_from_state_bit_for_bit(gpu, tmp_path, fdt
     assert a.scheduler.config.steps_offset == 1 and a.scheduler.config.set_alpha_to_one is False
     ori_img, coarse, _ = synth_images()
     ori, tgt, *_ = mask_inputs()
-    kw = dict(end_step=6, num_step=6, start_step=2, seed=42, end_scale=0.0, return_intermediates=True, verbose=False)
-    ia = a.FreeFine_generation(ori_img, ori, coarse, tgt, "a photo of a cup", 7.5, 1.0, **kw)
-    ib = b.FreeFine_generation(ori_img, ori, coarse, tgt, "a photo of a cup", 7.5, 1.0, **kw)
+    kw = dict(edit_cases()[0][2])                        # the first golden edit configuration (its masks / schedule), with a real prompt
+    kw.pop("guidance_text")
+    gs, eta = kw.pop("guidance_scale"), kw.pop("eta")
+    kw.update(seed=42, return_intermediates=True, verbose=False)
+    ia = a.FreeFine_generation(ori_img, ori, coarse, tgt, "a photo of a cup", gs, eta, **kw)
+    ib = b.FreeFine_generation(ori_img, ori, coarse, tgt, "a photo of a cup", gs, eta, **kw)
     assert len(a.last_intermediates) == len(b.last_intermediates) > 0
     for x, y in zip(a.last_intermediates, b.last_intermediates):
         assert torch.equal(x, y)
