@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FREEFINE_HIP_LIB") or os.path.join(_HERE, "libfreefine_hip.so")   # env override: A/B builds of the same ABI
 
 FFN_F32, FFN_BF16, FFN_BF16X3, FFN_FP8 = 0, 1, 2, 3
-IG_OUT_SILU, IG_OUT_F32, IG_GEGLU, IG_OUT_TRANSPOSED, IG_OUT_PAIR, IG_OUT_GELU, IG_OUT_RELU = 1, 2, 4, 8, 16, 32, 64
+IG_OUT_SILU, IG_OUT_F32, IG_GEGLU, IG_OUT_TRANSPOSED, IG_OUT_PAIR, IG_OUT_GELU, IG_OUT_RELU, IG_OUT_KV64 = 1, 2, 4, 8, 16, 32, 64, 128
 ELT_RELU, ELT_ADD = 0, 1
 ATT_MAXP, ATT_MAXB = 4, 16
 ATT_HEAD_RULE, ATT_UNIFORM_SEL1, ATT_UNIFORM_SEL0 = 1, 2, 4
@@ -27,7 +27,7 @@ class IgemmDesc(C.Structure):
         ("stride", C.c_int), ("pad", C.c_int), ("upsample", C.c_int),
         ("flags", C.c_int), ("alpha", C.c_float), ("conv", C.c_int),
         ("splitk", C.c_int), ("ws", C.c_void_p), ("ws_bytes", C.c_long),
-        ("a_lo", C.c_int), ("x3", C.c_int), ("f8", C.c_int),
+        ("a_lo", C.c_int), ("x3", C.c_int), ("f8", C.c_int), ("kv64_from", C.c_int),
     ]
 
 

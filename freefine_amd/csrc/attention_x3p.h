@@ -196,14 +196,14 @@ __global__ __launch_bounds__(512) void attn_x3p_kernel(const AttnParams p) {
         // c' ^ (r & 7) of key (K) / of d row (V^T) r; K rows are the key permutation row 16 tq + 4 gq + rr <-> key 32 (tq >> 1) + 8 gq + 4 (tq & 1) + rr
         const int dr = 8 * wave + (lane >> 3), dc = ((lane & 7) ^ (dr & 7)) * 16;
         const int dkey = 32 * (dr >> 5) + 8 * ((dr >> 2) & 3) + 4 * ((dr >> 4) & 1) + (dr & 3);
-        const int k_voff = dkey * p.heads * 256 + dc, v_voff = dr * (p.Sk / KT) * 256 + dc;
+        const int k_voff = dkey * p.ldk * 4 + dc, v_voff = dr * p.ldvt * 4 + dc;      // (ldk * 4 / ldvt * 4: bytes from key to key / from row to row of the images)
         const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.k), 0, PAIRKV ? 0x7ffff000 : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.vt), 0, PAIRKV ? 0x7ffff000 : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(en.kmask), 0, (PAIRKV && MASKS && pass_masked) ? p.Sk : 0, 0x00020000);
         auto dma_tile = [&](int t, int vs) {                    // tile t -> K slot t & 1, V^T slot vs (t >= ntiles: nothing)
             if (!PAIRKV || t >= ntiles) return;
-            const int ks = ((en.kv_row * p.Sk + t * KT) * p.heads + head) * 256;
-            const int vsoff = ((en.kv_row * p.heads * D + head * D) * (p.Sk / KT) + t) * 256;
+            const int ks = (en.kv_row * p.Sk + t * KT) * p.ldk * 4 + head * 256;
+            const int vsoff = (en.kv_row * p.heads * D + head * D) * p.ldvt * 4 + t * 256;
             char* Kd = smem + (t & 1) * SLOT + wave * 1024;
             char* Vd = smem + OFF_V + vs * SLOT + wave * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (att_lptr_t)Kd, 16, k_voff, ks, 0, 0);

@@ -35,7 +35,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) uint8_t x3w_lds_u8_t;
 
 #ifndef X3W_KRING
-#define X3W_KRING 6   // K ring slots (32-key blocks): 6 = requested two iterations ahead, the first fragments of an iteration read ahead of its barrier; 4 = one ahead
+#define X3W_KRING 4   // K ring slots (32-key blocks): 4 = a block is requested one iteration ahead of its first read (measured faster on the same box: 1368 vs 1401 us, profiles/r6_x3w_ring_depth_and_dma_placement_ab.txt); 6 = two ahead, first fragments read ahead of the barrier
 #endif
 #ifndef X3W_SPREAD
 #define X3W_SPREAD 0  // 1: the iteration's LDS-DMA requests ride the vector-free MFMA gaps of its two steps; 0: all at its start (faster: see the header of the key loop)
@@ -125,8 +125,9 @@ __global__ __launch_bounds__(256) void attn_x3w_kernel(const AttnParams p) {
     const int lr = lane >> 3;
     const int dchunk = (lane & 7) ^ (4 * (wave & 1) + (lr >> 1));
     const int dkey = (lr & 3) + 4 * (wave & 1) + 8 * (lr >> 2) + 16 * ((wave >> 1) & 1);    // pi(8 wave + lr): LDS row of a K block -> key of the block
-    const int k_voff = dkey * p.heads * 256 + dchunk * 16;
-    const int v_voff = (8 * wave + lr) * ntiles * 256 + dchunk * 16;
+    const int kst = p.ldk * 4, vst = p.ldvt * 4;                                              // bytes from key to key of the K image, from row to row of the V^T image
+    const int k_voff = dkey * kst + dchunk * 16;
+    const int v_voff = (8 * wave + lr) * vst + dchunk * 16;
     const int mrow = (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1);                            // pi(r): the key whose scores LDS row r holds
 
     for (int pass = 0; pass < p.npass; ++pass) {
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void attn_x3w_kernel(const AttnParams p) {
         const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.vt), 0, 0x7ffff000, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(en.kmask), 0, (MASKS && pass_masked) ? p.Sk : 0, 0x00020000);
         auto dma_kblk = [&](int bk, bool valid, int img) {      // img 0: hi image, 1: lo image
-            const int ks = valid ? ((en.kv_row * p.Sk + bk * 32) * p.heads + head) * 256 : 0;
+            const int ks = valid ? (en.kv_row * p.Sk + bk * 32) * kst + head * 256 : 0;
             const int vo = valid ? k_voff : OOB;
             char* Kd = smem + (bk % NKB) * KBLK + wave * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (att_lptr_t)(Kd + img * 4096), 16, vo, ks + img * 128, 0, 0);
@@ -199,10 +200,10 @@ __global__ __launch_bounds__(256) void attn_x3w_kernel(const AttnParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, (att_lptr_t)(smem + OFF_M + (t & 3) * 256), 4, valid ? m_voff : OOB, valid ? t * KT : 0, 0, 0);
         };
         auto dma_v = [&](int t, int piece) {                    // V^T tile t (< ntiles) -> slot t & 1; piece = image (hi / lo) + 2 * row half
-            const int vs = ((en.kv_row * p.heads * D + head * D) * ntiles + t) * 256;
+            const int vs = (en.kv_row * p.heads * D + head * D) * vst + t * 256;
             char* Vd = smem + OFF_V + (t & 1) * VSLOT + wave * 1024;
             const int img = piece & 1, half = piece >> 1;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (att_lptr_t)(Vd + img * VIMG + half * 4096), 16, v_voff, vs + img * 128 + half * 32 * ntiles * 256, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (att_lptr_t)(Vd + img * VIMG + half * 4096), 16, v_voff, vs + img * 128 + half * 32 * vst, 0, 0);
         };
         auto dma_done = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
         auto lds_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };

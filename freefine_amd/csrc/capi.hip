@@ -197,7 +197,7 @@ static int dispatch_igemm_tile(hipStream_t s, const ffn_igemm_desc& d) {
     return launch_igemm<T, 64, 64, AMODE, SWAP>(s, d, sk);
 }
 static bool can_split(const ffn_igemm_desc& d) {
-    return d.ws && d.splitk != 1 && !(d.flags & (FFN_IG_GEGLU | FFN_IG_OUT_TRANSPOSED));
+    return d.ws && d.splitk != 1 && !(d.flags & (FFN_IG_GEGLU | FFN_IG_OUT_TRANSPOSED | FFN_IG_OUT_KV64));
 }
 // tile + number of K slices.  Without split-K small-M problems take small tiles to fill the chip; with it they keep the
 // 128x128 tile (operand reuse) and the K loop is cut so that ~2 workgroups per CU exist.
@@ -281,7 +281,7 @@ static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn, int splitk = 1) {
     } else {
         // GELU / RELU: applied by the plain bf16 epilogue, whose accumulators start at the bias -- not beside a residual (it starts there too)
         const int act_ok = (!d.residual && !d.x3 && !d.f8 && !(d.flags & FFN_IG_GEGLU)) ? (FFN_IG_OUT_GELU | FFN_IG_OUT_RELU) : 0;
-        if ((d.alpha != 1.0f && !d.f8) || (d.flags & ~(FFN_IG_GEGLU | act_ok | (d.x3 ? (FFN_IG_OUT_F32 | FFN_IG_OUT_PAIR) : 0)))) return false;
+        if ((d.alpha != 1.0f && !d.f8) || (d.flags & ~(FFN_IG_GEGLU | act_ok | (d.x3 ? (FFN_IG_OUT_F32 | FFN_IG_OUT_PAIR | FFN_IG_OUT_KV64) : 0)))) return false;
         if (d.f8 && (!d.conv || (d.flags & FFN_IG_GEGLU))) return false;
         if (d.x3 && ((d.flags & FFN_IG_GEGLU) != 0) != ((d.flags & FFN_IG_OUT_PAIR) != 0)) return false;      // the split-bf16 GEGLU tile writes the pair form, nothing else does
         if ((d.flags & FFN_IG_GEGLU) && bn != 256) return false;
@@ -954,6 +954,15 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
     } else {
         REQUIRE(d->lda % epc == 0, "igemm: lda=%d must be a multiple of %d", d->lda, epc);
     }
+    if (d->flags & FFN_IG_OUT_KV64) {
+        REQUIRE(dtype == FFN_BF16X3 && !d->conv && !d->residual && !d->rowbias && d->splitk <= 1 &&
+                    !(d->flags & (FFN_IG_GEGLU | FFN_IG_OUT_PAIR | FFN_IG_OUT_SILU | FFN_IG_OUT_GELU | FFN_IG_OUT_RELU)),
+                "igemm: FFN_IG_OUT_KV64 needs FFN_BF16X3, dense A, the plain epilogue and no forced split-K");
+        if (d->flags & FFN_IG_OUT_TRANSPOSED) REQUIRE(d->rows_per_batch % 64 == 0 && d->M % d->rows_per_batch == 0 && d->ldo >= d->rows_per_batch && d->ldo % 64 == 0,
+                                                      "igemm: KV64 transposed output needs rows_per_batch %% 64 == 0, whole batches, ldo %% 64 == 0 (rows_per_batch=%d, ldo=%d)", d->rows_per_batch, d->ldo);
+        else REQUIRE(d->kv64_from >= 0 && d->kv64_from < d->N && d->kv64_from % 64 == 0 && d->N % 64 == 0 && d->ldo % 4 == 0,
+                     "igemm: KV64 output needs kv64_from and N %% 64 == 0 (kv64_from=%d, N=%d)", d->kv64_from, d->N);
+    }
     if (d->flags & FFN_IG_OUT_TRANSPOSED) {
         REQUIRE(d->ldo % 4 == 0, "igemm: transposed ldo=%d must be a multiple of 4", d->ldo);
         REQUIRE(!(d->flags & (FFN_IG_GEGLU | FFN_IG_OUT_F32 | FFN_IG_OUT_SILU | FFN_IG_OUT_GELU | FFN_IG_OUT_RELU)) && !d->residual && !d->rowbias,
@@ -1184,7 +1193,10 @@ extern "C" int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d) {
         long maxkv = 0;
         for (int pi = 0; pi < d->npass; ++pi)
             for (int b = 0; b < d->Bo; ++b) maxkv = d->e[pi * FFN_ATT_MAXB + b].kv_row > maxkv ? d->e[pi * FFN_ATT_MAXB + b].kv_row : maxkv;
-        REQUIRE((maxkv + 1) * d->Sk * d->heads * 256 < (1l << 31) - 65536, "attn: pre-split K / V^T images beyond 2 GiB (32-bit byte offsets)");
+        REQUIRE(d->ldk >= d->heads * 64 && d->ldk % 64 == 0 && d->ldvt >= d->Sk && d->ldvt % 64 == 0,
+                "attn: pre-split images need ldk >= heads * 64, ldvt >= Sk, both %% 64 == 0 (ldk=%d, ldvt=%d)", d->ldk, d->ldvt);
+        REQUIRE((maxkv + 1) * d->Sk * (long)d->ldk * 4 < (1l << 31) - 65536 && (maxkv + 1) * d->heads * 64 * (long)d->ldvt * 4 < (1l << 31) - 65536,
+                "attn: pre-split K / V^T images beyond 2 GiB (32-bit byte offsets)");
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int D = d->D;

@@ -23,7 +23,7 @@
 
 enum { AMODE_DENSE = 0, AMODE_CONV3 = 1 };
 enum { IG_OUT_SILU = FFN_IG_OUT_SILU, IG_OUT_F32 = FFN_IG_OUT_F32, IG_GEGLU = FFN_IG_GEGLU, IG_OUT_TRANSPOSED = FFN_IG_OUT_TRANSPOSED, IG_OUT_PAIR = FFN_IG_OUT_PAIR,
-       IG_OUT_GELU = FFN_IG_OUT_GELU, IG_OUT_RELU = FFN_IG_OUT_RELU };
+       IG_OUT_GELU = FFN_IG_OUT_GELU, IG_OUT_RELU = FFN_IG_OUT_RELU, IG_OUT_KV64 = FFN_IG_OUT_KV64 };
 // the plain epilogue's activation (flags are launch-uniform)
 __device__ __forceinline__ float ig_activation(float x, int flags) {
     if (flags & IG_OUT_SILU) return silu_exact(x);
@@ -42,6 +42,18 @@ __device__ __forceinline__ void store_pair_row4(bf16* row, int c, int C, const f
     lo[1] = pack_bf16x2(v[2] - __uint_as_float(hi[1] << 16), v[3] - __uint_as_float(hi[1] & 0xffff0000u));
     *reinterpret_cast<u32x2*>(p) = hi;
     *reinterpret_cast<u32x2*>(p + lo_off) = lo;
+}
+// FFN_IG_OUT_KV64 (include/freefine_hip.h): four values of 64-column block positions d .. d + 3 (d % 4 == 0) -> [hi(64) | lo(64)] bf16 at `blk` (the
+// 256 bytes the block's fp32 values would occupy): the pre-split K / V^T image of the split-bf16 attention kernels, written by the projection itself
+__device__ __forceinline__ void store_kv64_4(float* blk, int d, const float* v) {
+    bf16* p = reinterpret_cast<bf16*>(blk) + d;
+    u32x2 hi, lo;
+    hi[0] = pack_bf16x2(v[0], v[1]);
+    hi[1] = pack_bf16x2(v[2], v[3]);
+    lo[0] = pack_bf16x2(v[0] - __uint_as_float(hi[0] << 16), v[1] - __uint_as_float(hi[0] & 0xffff0000u));
+    lo[1] = pack_bf16x2(v[2] - __uint_as_float(hi[1] << 16), v[3] - __uint_as_float(hi[1] & 0xffff0000u));
+    *reinterpret_cast<u32x2*>(p) = hi;
+    *reinterpret_cast<u32x2*>(p + 64) = lo;
 }
 typedef ffn_igemm_desc IgemmParams;
 
@@ -125,6 +137,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
                         }
                         if (p.flags & IG_OUT_PAIR)
                             store_pair_row4(reinterpret_cast<bf16*>(p.out) + (long)m * p.ldo, n, p.ldo / 2, v);
+                        else if ((p.flags & IG_OUT_KV64) && n >= p.kv64_from)
+                            store_kv64_4(outF + (long)m * p.ldo + p.kv64_from + ((n - p.kv64_from) & ~63), (n - p.kv64_from) & 63, v);
                         else if (out_f32)
                             store4(outF + (long)m * p.ldo + n, v);
                         else
@@ -151,7 +165,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
                 }
                 if (p.flags & IG_OUT_TRANSPOSED) {
                     const int bb = mb / p.rows_per_batch, s = mb - bb * p.rows_per_batch;
-                    if ((p.rows_per_batch & 3) == 0 && mb + 3 < p.M) {
+                    if ((p.flags & IG_OUT_KV64) && mb < p.M) {      // (fp32-typed launches only; rows_per_batch % 64 == 0, so M % 4 == 0)
+                        store_kv64_4(outF + ((long)bb * p.N + n) * p.ldo + (s & ~63), s & 63, v);
+                    } else if ((p.rows_per_batch & 3) == 0 && mb + 3 < p.M) {
                         store4(outT + ((long)bb * p.N + n) * p.ldo + s, v);
                     } else {
 #pragma unroll

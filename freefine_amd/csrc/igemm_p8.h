@@ -493,6 +493,19 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
                     if constexpr (X3) {               // fp32 V^T (the split-bf16 attention kernels read fp32 operands): 16 bytes per lane
                         u32x4 w4 = __builtin_bit_cast(u32x4, acc[i][j]);
                         w4[0] = perm(w4[0]); w4[1] = perm(w4[1]); w4[2] = perm(w4[2]); w4[3] = perm(w4[3]);
+                        if (p.flags & FFN_IG_OUT_KV64) {      // the attention kernels' pre-split V^T image: positions s .. s + 3 of key tile s / 64 -> hi 8 bytes, lo 8 bytes
+                            const float f0 = __uint_as_float(w4[0]), f1 = __uint_as_float(w4[1]), f2 = __uint_as_float(w4[2]), f3 = __uint_as_float(w4[3]);
+                            u32x2 hi, lo;
+                            hi[0] = pack_bf16x2(f0, f1);
+                            hi[1] = pack_bf16x2(f2, f3);
+                            lo[0] = pack_bf16x2(f0 - __uint_as_float(hi[0] << 16), f1 - __uint_as_float(hi[0] & 0xffff0000u));
+                            lo[1] = pack_bf16x2(f2 - __uint_as_float(hi[1] << 16), f3 - __uint_as_float(hi[1] & 0xffff0000u));
+                            const int vo2 = mb + 4 * pg < p.M ? (pr * p.ldo * 4 + 4 * pg * 2) : OOB;
+                            const int so2 = (bb * p.N + n0 + j * 16) * p.ldo * 4 + (sb >> 6) * 256 + (sb & 63) * 2;
+                            __builtin_amdgcn_raw_buffer_store_b64(hi, rsrcO, vo2, so2, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(lo, rsrcO, vo2, so2 + 128, 0);
+                            continue;
+                        }
                         __builtin_amdgcn_raw_buffer_store_b128(w4, rsrcO, mb + 4 * pg < p.M ? voff : OOB, ((bb * p.N + n0 + j * 16) * p.ldo + sb) * 4, 0);
                         continue;
                     }
@@ -539,6 +552,21 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
                     for (int j = 0; j < FN; ++j) {
                         u32x4 w = __builtin_bit_cast(u32x4, acc[i][j]);
                         w[0] = perm(w[0]); w[1] = perm(w[1]); w[2] = perm(w[2]); w[3] = perm(w[3]);
+                        const int nf = n0 + j * 16;           // first column of the fragment (a fragment never straddles a 64-column block)
+                        if ((p.flags & FFN_IG_OUT_KV64) && nf >= p.kv64_from) {      // the attention kernels' pre-split K image: [hi(64) | lo(64)] per head
+                            const float f0 = __uint_as_float(w[0]), f1 = __uint_as_float(w[1]), f2 = __uint_as_float(w[2]), f3 = __uint_as_float(w[3]);
+                            u32x2 hi, lo;
+                            hi[0] = pack_bf16x2(f0, f1);
+                            hi[1] = pack_bf16x2(f2, f3);
+                            lo[0] = pack_bf16x2(f0 - __uint_as_float(hi[0] << 16), f1 - __uint_as_float(hi[0] & 0xffff0000u));
+                            lo[1] = pack_bf16x2(f2 - __uint_as_float(hi[1] << 16), f3 - __uint_as_float(hi[1] & 0xffff0000u));
+                            const int crel = nf - p.kv64_from;
+                            const int vo2 = m0 + i * 16 + pr < p.M ? (pr * p.ldo * 4 + 4 * pg * 2) : OOB;
+                            const int so2 = ((m0 + i * 16) * p.ldo + p.kv64_from) * 4 + (crel >> 6) * 256 + (crel & 63) * 2;
+                            __builtin_amdgcn_raw_buffer_store_b64(hi, rsrcO, vo2, so2, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(lo, rsrcO, vo2, so2 + 128, 0);
+                            continue;
+                        }
                         __builtin_amdgcn_raw_buffer_store_b128(w, rsrcO, vo, ((m0 + i * 16) * p.ldo + n0 + j * 16) * 4, 0);
                     }
                 }

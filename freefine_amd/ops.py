@@ -87,6 +87,7 @@ def _igemm_name(lib, dcode, d):
 # weight packing (host side, once at load time)
 # ---------------------------------------------------------------------------------------------------------------
 _GN_CHUNK_MB = float(os.environ.get("FFN_GN_CHUNK_MB", "0"))           # GroupNorm row chunks (MiB of input per chunk; 0 = whole batch at once)
+_KV64 = os.environ.get("FFN_KV64", "1") != "0"                         # self-attention K / V^T projections write the pre-split images themselves (0: fp32 + ffn_attn_presplit)
 _ATTN_PRESPLIT = os.environ.get("FFN_ATTN_PRESPLIT", "1") != "0"      # split-bf16 self attention: pre-split K / V^T once per call (0: split inside the kernel's key loop)
 
 
@@ -335,8 +336,11 @@ def _workspace(device):
     return ws
 
 def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, rows_per_batch=None, silu=False,
-           geglu=False, out_f32=False, transposed_ld=None, alpha=1.0, splitk=0, out_pair=False, gelu=False, relu=False):
-    """out = x @ w[:, :K]^T (+bias ...).  x: [..., K] contiguous rows (M = prod of leading dims)."""
+           geglu=False, out_f32=False, transposed_ld=None, alpha=1.0, splitk=0, out_pair=False, gelu=False, relu=False, kv64_from=None):
+    """out = x @ w[:, :K]^T (+bias ...).  x: [..., K] contiguous rows (M = prod of leading dims).
+    kv64_from (split-bf16 only): the projection writes the attention kernels' pre-split K / V^T images itself (FFN_IG_OUT_KV64): row-major output --
+    columns >= kv64_from of every row as [hi(64) | lo(64)] blocks per head in the bytes of their fp32 values; transposed output (any value, use 0) --
+    every run of 64 positions of a row as one such block.  The caller hands such buffers to ops.attention(kv_images=True)."""
     lib = L.load()
     K = K if K is not None else x.shape[-1]
     M = x.numel() // x.shape[-1]
@@ -392,6 +396,11 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
         d.ldo = out.stride(-2) if out.ndim > 1 else n_out          # a column view of a wider buffer (cat_dst) keeps the buffer's row stride
     d.ldr = residual.shape[-1] if residual is not None else 0
     d.out = out.data_ptr()
+    if kv64_from is not None:
+        assert x3 and residual is None and rowbias is None and not (silu or gelu or relu or geglu or out_pair)
+        flags |= L.IG_OUT_KV64
+        d.kv64_from = int(kv64_from)
+        splitk = 1
     d.flags, d.alpha, d.conv = flags, alpha, 0
     d.splitk, d.ws, d.ws_bytes = splitk, _workspace(x.device).data_ptr(), WS_BYTES
     if _PROF is None:
@@ -489,10 +498,25 @@ class AttnEntrySpec:
                              self.kmask, self.qsel, self.flags, logical_row if self.hr_row is None else self.hr_row)
 
 
-def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=None, Bo=None, C=None, x3=False, out_pair=False):
+def kv_images_ok(Dh, S, Sk, passes=None, nbytes=0):
+    """split-bf16 self attention whose K / V^T projections may write the attention kernel's pre-split images themselves (linear(kv64_from=...),
+    attention(kv_images=True)): the shapes attn_x3w_kernel / attn_x3p_kernel take, a plan without degenerate uniform-softmax entries (those run on
+    attn_x3_kernel, which reads fp32 K / V^T), and buffers the kernels' 32-bit byte offsets reach (nbytes = the larger of the K and V^T buffers)"""
+    if not (_ATTN_PRESPLIT and _KV64 and Dh == 64 and Sk % 64 == 0 and S >= 128 and nbytes < 2 ** 31 - 65536):
+        return False
+    for rows in passes or ():
+        for sp in rows:
+            if sp is not None and (sp.w_const != 0.0 or sp.w_slope != 0.0) and sp.kmask is not None and (sp.flags & (L.ATT_UNIFORM_SEL1 | L.ATT_UNIFORM_SEL0)):
+                return False
+    return True
+
+
+def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=None, Bo=None, C=None, x3=False, out_pair=False, kv_images=False):
     """q: [Bq,S,C]; k: [Bk,Sk,C]; vt: [Bk,C,ldvt] (V transposed).  passes: list (per pass) of lists (per output
     row) of AttnEntrySpec or None (= skipped).  passes=None -> plain attention, row b uses its own K/V.
-    More than FFN_ATT_MAXB output rows are issued as several launches over row ranges (entries name absolute Q/KV rows)."""
+    More than FFN_ATT_MAXB output rows are issued as several launches over row ranges (entries name absolute Q/KV rows).
+    kv_images (split-bf16 self attention): k / vt already ARE the pre-split images (written by their projections with kv64_from: fp32-typed tensors of
+    the shapes above whose bytes hold [hi(64) | lo(64)] blocks); the launches run with kv_pair = 1 and no ffn_attn_presplit pass."""
     lib = L.load()
     Bq, S, _ = q.shape
     Cq = C if C is not None else q.shape[2]          # q / k may be column views of a wider [B,S,ld] buffer
@@ -520,6 +544,7 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
         d.ldq, d.ldk, d.ldvt, d.ldo = q.stride(1), k.stride(1), vt.stride(1), (2 * Cq if out_pair else Cq)
         d.out_pair = 1 if out_pair else 0
         d.scale, d.npass = scale, len(passes)
+        d.kv_pair = 1 if kv_images else 0
         for p, rows in enumerate(passes):
             for b in range(nb):
                 sp = rows[b0 + b]
@@ -536,7 +561,9 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
     # split-bf16 self attention on the ping-pong kernel: K / V^T are split ONCE per call into the bf16 images the kernel stages by LDS-DMA
     # (ffn_attn_presplit; the kernel's 16 query-block workgroups per (row, head) otherwise each split the whole K / V^T in their key loops)
     # (the images are addressed with 32-bit byte offsets: K / V^T beyond 2 GiB keep the in-kernel split instead of failing in ffn_attn)
-    if dcode == L.FFN_BF16X3 and _ATTN_PRESPLIT and Dh == 64 and Sk % 64 == 0 and S >= 128 and k.stride(2) == 1 and vt.stride(2) == 1 \
+    if kv_images:
+        assert dcode == L.FFN_BF16X3 and kv_images_ok(Dh, S, Sk)
+    elif dcode == L.FFN_BF16X3 and _ATTN_PRESPLIT and Dh == 64 and Sk % 64 == 0 and S >= 128 and k.stride(2) == 1 and vt.stride(2) == 1 \
             and k.stride(0) == Sk * k.stride(1) and vt.stride(0) == heads * Dh * vt.stride(1) and k.shape[0] * Sk * heads * 256 < 2 ** 31 - 65536:
         nbuf = CT.create_string_buffer(160)
         names = []
@@ -552,6 +579,7 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
                     "ffn_attn_presplit")
             for _, _, d in descs:
                 d.k, d.vt, d.kv_pair = kp.data_ptr(), vp.data_ptr(), 1
+                d.ldk, d.ldvt = heads * Dh, Sk              # compact images: the strides of the fp32 tensors they replace
     for b0, nb, d in descs:
         if _PROF is None:
             L.check(lib.ffn_attn(_stream(), dcode, CT.byref(d)), "ffn_attn")

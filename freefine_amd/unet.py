@@ -615,24 +615,34 @@ class HipUNet:
         out["passes"] = [[pin(rows[r], r) for r in keep] for rows in passes]
         return out
 
-    def _attention(self, t, is_cross, place, q, k, vt, ldq_view, B, S, Sk, drop_ref_queries=False):
-        D = t.C // t.heads
-        scale = D ** -0.5
+    def _self_plan(self, t, place, B, S, drop_ref_queries=False):
+        """plan of a block's self attention, made BEFORE its K / V^T projections run (the controllers' layer counters advance once per attention
+        call, in call order): None without a controller and without dropped rows"""
         if self.controller is None:
-            passes = [[ops.AttnEntrySpec(r, r, hr_row=r) for r in self._reuse["idx_a_list"]]] if drop_ref_queries else None
-            return ops.attention(q, k, vt, t.heads, scale, passes, Sk=Sk, C=t.C, x3=self.x3, out_pair=self.x3)
-        plan = self._plan(is_cross, place, B, S, t.heads)
+            return dict(kind="plain", needs_cg=False, passes=[[ops.AttnEntrySpec(r, r, hr_row=r) for r in self._reuse["idx_a_list"]]]) if drop_ref_queries else None
+        plan = self._plan(False, place, B, S, t.heads)
         if drop_ref_queries:
             assert plan["kind"] != "shared_kv"
             plan = self._without_ref_queries(plan, B)
+        return plan
+
+    def _attention(self, t, is_cross, place, q, k, vt, ldq_view, B, S, Sk, plan=None, kv_images=False):
+        """plan: a self-attention plan made by _self_plan (cross attention plans here)"""
+        D = t.C // t.heads
+        scale = D ** -0.5
+        if is_cross and self.controller is not None:
+            plan = self._plan(is_cross, place, B, S, t.heads)
+        if plan is None:
+            return ops.attention(q, k, vt, t.heads, scale, None, Sk=Sk, C=t.C, x3=self.x3, out_pair=self.x3, kv_images=kv_images)
         if plan["kind"] == "shared_kv":
+            assert not kv_images
             rr = plan["ref_rows"]
             kc = k[..., :t.C] if k.shape[-1] != t.C else k
             k2 = torch.cat([kc, kc[rr]], dim=1).contiguous()                 # device-memory plumbing (non-default SSA/SDSA path)
             vt2 = torch.cat([vt[..., :Sk], vt[rr][..., :Sk]], dim=2).contiguous()
             return ops.attention(q, k2, vt2, t.heads, scale, plan["passes"], Sk=2 * Sk, C=t.C, x3=self.x3, out_pair=self.x3)
         return ops.attention(q, k, vt, t.heads, scale, plan["passes"], Sk=Sk, C=t.C, w_dev=self.cg_dev if plan["needs_cg"] else None, x3=self.x3,
-                             out_pair=self.x3)
+                             out_pair=self.x3, kv_images=kv_images)
 
     def _kv_buffers(self, B, S, C, ldv):
         """stored-K/V forward, next recorded block: (q|k [B + n_ref, S, 2C], V^T [B + n_ref, C, ldv]) whose last n_ref rows hold the recorded
@@ -673,14 +683,21 @@ class HipUNet:
             ops.linear(y, t.w_qk1, None, K=C, out=qk[:B])
             ops.linear(y, t.w_v1, None, K=C, rows_per_batch=S, transposed_ld=ldv, out=vt[:B])
             self._kv_ext = True
-            a = self._attention(t, False, place, qk[:B], qk[..., C:], vt, 2 * C, B, S, S)
+            a = self._attention(t, False, place, qk[:B], qk[..., C:], vt, 2 * C, B, S, S, plan=self._self_plan(t, place, B, S))
             self._kv_ext = False
         else:
-            qk = ops.linear(y, t.w_qk1, None, K=C)                              # [B,S,2C]: q | k
-            vt = ops.linear(y, t.w_v1, None, K=C, rows_per_batch=S, transposed_ld=ldv)           # V^T [B,C,S]
-            if ru is not None and ru["mode"] == "record" and ru.get("kv_from") is not None and tb >= ru["kv_from"]:
+            plan = self._self_plan(t, place, B, S, drop_ref_queries=drop is not None)
+            rec = ru is not None and ru["mode"] == "record" and ru.get("kv_from") is not None and tb >= ru["kv_from"]
+            # split-bf16: the K and V^T projections write the attention kernel's pre-split [hi | lo] images in the bytes of the fp32 values they replace
+            # (no ffn_attn_presplit pass).  Not for recorded K / V (a later stored-K/V forward reads them as fp32, under a plan unknown here) nor for
+            # the shared-K/V plans (their K / V are gathered as fp32 tensors).
+            img = self.x3 and not rec and (plan is None or plan["kind"] != "shared_kv") and \
+                ops.kv_images_ok(C // t.heads, S, S, None if plan is None else plan["passes"], B * max(S * 2 * C, C * ldv) * 4)
+            qk = ops.linear(y, t.w_qk1, None, K=C, kv64_from=C if img else None)        # [B,S,2C]: q | k
+            vt = ops.linear(y, t.w_v1, None, K=C, rows_per_batch=S, transposed_ld=ldv, kv64_from=0 if img else None)           # V^T [B,C,S]
+            if rec:
                 self.last_kv.append((qk[..., C:], vt))
-            a = self._attention(t, False, place, qk, qk[..., C:], vt, 2 * C, B, S, S, drop_ref_queries=drop is not None)
+            a = self._attention(t, False, place, qk, qk[..., C:], vt, 2 * C, B, S, S, plan=plan, kv_images=img)
         if drop is not None:                                 # `a` already holds the surviving rows only; the residual streams follow
             idx, kv_text = drop
             h, res0, B = h.index_select(0, idx), res0.index_select(0, idx), idx.shape[0]

@@ -56,6 +56,12 @@ enum {
     FFN_IG_OUT_PAIR = 1 << 4,       /* FFN_BF16X3 only: out is the bf16 PAIR form [M][ldo] of rows of C = ldo/2 columns (layout: FFN_BF16X3 below) -- the A
                                        operand of the next FFN_BF16X3 GEMM (the GEGLU projection feeding ff.net.2); no residual */
     FFN_IG_OUT_GELU = 1 << 5,       /* out = gelu_erf(acc + bias) (+ residual): the MLP of the DINOv2 blocks (dinov2/layers/mlp.py:31-38) */
+    FFN_IG_OUT_KV64 = 1 << 7,       /* FFN_BF16X3 only (round 6): the projection writes the attention kernels' PRE-SPLIT K / V^T images itself (what ffn_attn_presplit
+                                       produces from an fp32 K / V^T: one fp32 round trip and one HBM-bound pass less per self-attention block).  Row-major output:
+                                       columns c >= kv64_from of a row are stored, per 64 columns (one head), as [hi(64) | lo(64)] bf16 in the bytes their fp32 values
+                                       would occupy (columns below kv64_from stay fp32: the q half of the fused q | k projection; kv64_from and N %% 64 == 0).
+                                       FFN_IG_OUT_TRANSPOSED: every run of 64 consecutive positions s of a row out[b][n][.] is stored as [hi(64) | lo(64)]
+                                       (rows_per_batch %% 64 == 0).  Plain epilogue only (bias allowed), no split-K.  ffn_attn reads them with kv_pair = 1. */
     FFN_IG_OUT_RELU = 1 << 6        /* out = max(acc + bias, 0) (+ residual): the DPT head's ResidualConvUnit / output convs (depth_anything/blocks.py:68-78,
                                        dpt.py:93-98).  SILU / GELU / RELU are mutually exclusive and exclude GEGLU and the transposed output */
 };
@@ -84,6 +90,7 @@ typedef struct ffn_igemm_desc {
                          2 = blocked: A and W as 128-byte blocks [hi(32) | lo(32)] per 32 elements of K (needs K, conv: Cin, % 32 == 0; what the
                          ping-pong tile's split-bf16 core streams) */
     int f8;           /* set by the library from `dtype` (callers leave it 0) */
+    int kv64_from;    /* FFN_IG_OUT_KV64, row-major output: first column written in the pre-split form (0 = the whole row) */
 } ffn_igemm_desc;
 int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d);
 /* FFN_BF16X3 ("split-bf16", the fast mode that keeps fp32-level results): every fp32 operand value v is carried as hi = bf16(v) and
@@ -177,8 +184,11 @@ typedef struct ffn_attn_desc {
     int out_pair;       /* FFN_BF16X3 with D <= 64 only: out is the bf16 PAIR form [Bo][S][ldo] of rows of ldo/2 columns (layout: FFN_BF16X3 above), the A operand of
                            the to_out projection's FFN_BF16X3 GEMM; 0 = fp32 rows */
     int kv_pair;        /* FFN_BF16X3 launches that run attn_x3p_kernel (ffn_attn_kernel_name with kv_pair = 0 says so) only: k / vt are the PRE-SPLIT bf16
-                           images ffn_attn_presplit wrote (ldk / ldvt ignored; the launch then runs attn_x3w_kernel, attention_x3w.h -- round 6: one wave
-                           per SIMD on 32x32x16 MFMAs -- or, with FFN_ATTN_X3W=0 in the environment, attn_x3p_kernel<., PAIRKV>); 0 = fp32 k / vt */
+                           images ffn_attn_presplit (or a projection with FFN_IG_OUT_KV64) wrote: k[row][key] = heads blocks of [hi(64) | lo(64)], ldk * 4
+                           bytes from key to key; vt[row][head * 64 + d] = Sk / 64 blocks of [hi(64 keys) | lo(64 keys)], ldvt * 4 bytes from row to row
+                           (i.e. ldk / ldvt are what they would be for the fp32 tensors the images replace: heads * 64 / Sk when compact).  The launch runs
+                           attn_x3w_kernel (attention_x3w.h, round 6: one wave per SIMD on 32x32x16 MFMAs) or, with FFN_ATTN_X3W=0 in the environment,
+                           attn_x3p_kernel<., PAIRKV>; 0 = fp32 k / vt */
     ffn_attn_entry e[FFN_ATT_MAXP * FFN_ATT_MAXB]; /* entry (p,b) at p*FFN_ATT_MAXB + b */
 } ffn_attn_desc;
 int ffn_attn(void* stream, int dtype, const ffn_attn_desc* d);

@@ -1255,6 +1255,86 @@ def test_x3_attention_presplit_kv_is_bit_identical(gpu, monkeypatch, S, heads, p
         assert relerr(outs[True], ref) < X3_TOL and relerr(ow, ref) < X3_TOL
 
 
+@pytest.mark.parametrize("tuned", [False, True])
+@pytest.mark.parametrize("B,S,heads,pairA", [(8, 4096, 5, True), (3, 4096, 5, True), (12, 1024, 10, True), (3, 1024, 10, False), (24, 256, 20, True), (3, 128, 5, True)])
+def test_x3_kv64_projections_write_the_presplit_images(gpu, B, S, heads, pairA, tuned):
+    """FFN_IG_OUT_KV64 (round 6): the self-attention K projection (the k half of the fused q|k GEMM, row-major) and the V^T projection (transposed
+    output) write the attention kernels' pre-split [hi(64) | lo(64)] images in the bytes of the fp32 values they replace.
+    tuned = False (ffn_igemm_tune_enable(0): the heuristic tile, the same kernel with and without the flag -- ping-pong tiles for the large batches,
+    the two-stage tile for the small ones): against ffn_attn_presplit of the plain fp32 projections the images agree BIT FOR BIT, the q half is
+    untouched, and attention over the strided images (kv_images=True) is bit-equal to the presplit path.
+    tuned = True (the timing-based tile choice may differ between the two launches, i.e. fp32 summation order): the images decode (hi + lo) to the fp32
+    projections within the pair form's 2^-16 and attention agrees to the split-bf16 tolerance.  All UNet levels' widths (C = 320 / 640 / 1280)."""
+    from freefine_amd import _lib, ops
+    g = torch.Generator().manual_seed(S + heads)
+    D = 64
+    C = heads * D
+    lib = _lib.load()
+    y = rnd((B, S, C), torch.float32, gpu, g)
+    wqk = ops.pack_linear(rnd((2 * C, C), torch.float32, gpu, g, C ** -0.5), torch.float32, x3=True)
+    wv = ops.pack_linear(rnd((C, C), torch.float32, gpu, g, C ** -0.5), torch.float32, x3=True)
+    ya = ops.layernorm(y, torch.ones(C, device=gpu), torch.zeros(C, device=gpu), pair=True) if pairA else y
+    prev = lib.ffn_igemm_tune_enable(1 if tuned else 0)
+    try:
+        qk = ops.linear(ya, wqk, None, K=C, splitk=1)             # (the image-writing launches never take the split-K form)
+        vt = ops.linear(ya, wv, None, K=C, rows_per_batch=S, transposed_ld=S)
+        qk_i = ops.linear(ya, wqk, None, K=C, kv64_from=C)
+        vt_i = ops.linear(ya, wv, None, K=C, rows_per_batch=S, transposed_ld=S, kv64_from=0)
+    finally:
+        lib.ffn_igemm_tune_enable(prev)
+    assert qk_i.shape == qk.shape and vt_i.shape == vt.shape and qk_i.dtype == torch.float32
+    kp = torch.empty(B, S, 2 * C, dtype=torch.bfloat16, device=gpu)
+    vp = torch.empty(B, C, 2 * S, dtype=torch.bfloat16, device=gpu)
+    _lib.check(lib.ffn_attn_presplit(ops._stream(), qk[..., C:].data_ptr(), vt.data_ptr(), kp.data_ptr(), vp.data_ptr(), B, S, heads, 2 * C, S), "ffn_attn_presplit")
+    ki = qk_i.view(torch.bfloat16)[..., 2 * C:]                  # [B, S, 2C] bf16: per head [hi(64) | lo(64)]
+    vi = vt_i.view(torch.bfloat16)                               # [B, C, 2S] bf16: per 64 keys [hi(64) | lo(64)]
+    if not tuned:
+        assert torch.equal(qk_i[..., :C], qk[..., :C])           # the q half: plain fp32
+        assert torch.equal(ki.view(torch.int16), kp.view(torch.int16))
+        assert torch.equal(vi.view(torch.int16), vp.view(torch.int16))
+    else:
+        assert relerr(qk_i[..., :C], qk[..., :C].double()) < 2e-6
+        kd = ki.reshape(B, S, heads, 2, 64).float().sum(3).reshape(B, S, C)
+        vd = vi.reshape(B, C, S // 64, 2, 64).float().sum(3).reshape(B, C, S)
+        assert relerr(kd, qk[..., C:].double()) < 2e-5 and relerr(vd, vt.double()) < 2e-5
+        assert (kd - qk[..., C:]).abs().max() < 1e-4 and (vd - vt).abs().max() < 1e-4           # no misplaced element
+    # attention over the images where they lie (K image rows 2C fp32 apart, inside the q|k buffer)
+    km = (torch.rand(S, generator=g) > 0.6).to(torch.uint8).to(gpu)
+    Ba = min(B, 4)
+    P = [[ops.AttnEntrySpec(b, (b + 1) % Ba, 0.0, 1.0, kmask=km) for b in range(Ba)], [ops.AttnEntrySpec(b, b, 1.0, -1.0) for b in range(Ba)]]
+    cg = torch.tensor([0.4], dtype=torch.float32, device=gpu)
+    scale = D ** -0.5
+    for passes in ([[ops.AttnEntrySpec(b, b) for b in range(Ba)]], P):
+        assert ops.kv_images_ok(D, S, S, passes)
+        ref = ops.attention(qk, qk[..., C:], vt, heads, scale, passes, Sk=S, C=C, w_dev=cg, x3=True)
+        img = ops.attention(qk_i, qk_i[..., C:], vt_i, heads, scale, passes, Sk=S, C=C, w_dev=cg, x3=True, kv_images=True)
+        if not tuned:
+            assert torch.equal(ref, img)
+        else:
+            assert relerr(img, ref.double()) < X3_ATT_TOL
+    # a plan with a degenerate uniform-softmax entry runs on the fp32-operand kernel: not eligible
+    Pu = [[ops.AttnEntrySpec(b, b, 1.0, 0.0, kmask=km, flags=_lib.ATT_UNIFORM_SEL1) for b in range(Ba)]]
+    assert not ops.kv_images_ok(D, S, S, Pu)
+    assert not ops.kv_images_ok(D, S, S, None, 2 ** 31) and not ops.kv_images_ok(40, S, S) and not ops.kv_images_ok(D, 64, 64)
+
+
+def test_x3_kv64_rejects_what_it_cannot_write(gpu):
+    """the C ABI refuses FFN_IG_OUT_KV64 outside its contract instead of writing a wrong image: not split-bf16, an epilogue with bias-free extras,
+    widths that are not whole 64-blocks"""
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(2)
+    C, S = 320, 128
+    y = rnd((1, S, C), torch.float32, gpu, g)
+    w = ops.pack_linear(rnd((2 * C, C), torch.float32, gpu, g, C ** -0.5), torch.float32, x3=True)
+    with pytest.raises(RuntimeError):
+        ops.linear(y, w, None, K=C, kv64_from=C + 32)                                       # not a 64-column boundary
+    with pytest.raises(RuntimeError):
+        ops.linear(y, w, None, K=C, rows_per_batch=S, transposed_ld=S + 8, kv64_from=0)     # row stride not whole blocks
+    wf = ops.pack_linear(rnd((2 * C, C), torch.float32, gpu, g, C ** -0.5), torch.float32)
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.linear(y, wf, None, K=C, kv64_from=C)                                           # fp32 arithmetic: no images
+
+
 def test_x3_pair_producers_write_the_blocked_layout(gpu):
     """every producer of split-bf16 pair rows writes the layout ffn_split_pair writes (128-byte blocks [hi(32) | lo(32)] for C % 32 == 0):
     GroupNorm (three-launch and fused forms), LayerNorm, the GEGLU projection's pair output and the attention output -- each against the split
