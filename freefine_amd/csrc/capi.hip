@@ -283,7 +283,8 @@ static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn, int splitk = 1) {
         const int act_ok = (!d.residual && !d.x3 && !d.f8 && !(d.flags & FFN_IG_GEGLU)) ? (FFN_IG_OUT_GELU | FFN_IG_OUT_RELU) : 0;
         if ((d.alpha != 1.0f && !d.f8) || (d.flags & ~(FFN_IG_GEGLU | act_ok | (d.x3 ? (FFN_IG_OUT_F32 | FFN_IG_OUT_PAIR | FFN_IG_OUT_KV64) : 0)))) return false;
         if (d.f8 && (!d.conv || (d.flags & FFN_IG_GEGLU))) return false;
-        if (d.x3 && ((d.flags & FFN_IG_GEGLU) != 0) != ((d.flags & FFN_IG_OUT_PAIR) != 0)) return false;      // the split-bf16 GEGLU tile writes the pair form, nothing else does
+        if (d.x3 && (d.flags & FFN_IG_GEGLU) && !(d.flags & FFN_IG_OUT_PAIR)) return false;      // the split-bf16 GEGLU tile writes the pair form only
+        if ((d.flags & FFN_IG_OUT_PAIR) && !(d.flags & FFN_IG_GEGLU) && (d.N % 32 != 0 || (d.ldo / 2) % 32 != 0 || (d.flags & FFN_IG_OUT_TRANSPOSED))) return false;      // plain tile: blocked pair rows only
         if ((d.flags & FFN_IG_GEGLU) && bn != 256) return false;
         if (d.rowbias && d.rows_per_batch < 128) return false;      // a wave's rows (bm / 2) may straddle two images, not three
     }
@@ -972,7 +973,8 @@ extern "C" int ffn_igemm(void* stream, int dtype, const ffn_igemm_desc* d) {
         if (d->residual) REQUIRE(d->ldr % 4 == 0, "igemm: ldr=%d must be a multiple of 4", d->ldr);
         if (d->flags & FFN_IG_OUT_PAIR) {
             const int nout = (d->flags & FFN_IG_GEGLU) ? d->N / 2 : d->N;
-            REQUIRE(dtype == FFN_BF16X3 && !d->residual && d->ldo % 16 == 0 && d->ldo / 2 >= nout, "igemm: pair output needs FFN_BF16X3, no residual, ldo %% 16 == 0, ldo/2 >= columns");
+            REQUIRE(dtype == FFN_BF16X3 && d->ldo % 16 == 0 && d->ldo / 2 >= nout, "igemm: pair output needs FFN_BF16X3, ldo %% 16 == 0, ldo/2 >= columns");
+            REQUIRE(d->residual != d->out, "igemm: pair output cannot overwrite its fp32 residual");
             REQUIRE((d->ldo / 2) % 32 != 0 || nout % 32 == 0 || nout == d->ldo / 2, "igemm: blocked pair output (ldo/2 %% 32 == 0) needs whole 32-column blocks");
             // every producer derives the layout (blocked / planes) from the ROW WIDTH ldo / 2; the ping-pong GEGLU epilogue always writes blocked rows
             REQUIRE(nout == d->ldo / 2 || (d->ldo / 2) % 32 == 0, "igemm: pair output into a wider row needs ldo/2 %% 32 == 0 (ldo=%d, columns=%d)", d->ldo, nout);

@@ -552,7 +552,21 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
                     for (int j = 0; j < FN; ++j) {
                         u32x4 w = __builtin_bit_cast(u32x4, acc[i][j]);
                         w[0] = perm(w[0]); w[1] = perm(w[1]); w[2] = perm(w[2]); w[3] = perm(w[3]);
-                        const int nf = n0 + j * 16;           // first column of the fragment (a fragment never straddles a 64-column block)
+                        const int nf = n0 + j * 16;           // first column of the fragment (a fragment never straddles a 32- or 64-column block)
+                        if (p.flags & FFN_IG_OUT_PAIR) {      // blocked pair rows for the next split-bf16 GEMM (bias / residual already in the accumulators): out is
+                                                              // bf16 [M][ldo], columns 32 b .. 32 b + 31 = ONE 128-byte block [hi(32) | lo(32)] at element 64 b
+                            const float f0 = __uint_as_float(w[0]), f1 = __uint_as_float(w[1]), f2 = __uint_as_float(w[2]), f3 = __uint_as_float(w[3]);
+                            u32x2 hi, lo;
+                            hi[0] = pack_bf16x2(f0, f1);
+                            hi[1] = pack_bf16x2(f2, f3);
+                            lo[0] = pack_bf16x2(f0 - __uint_as_float(hi[0] << 16), f1 - __uint_as_float(hi[0] & 0xffff0000u));
+                            lo[1] = pack_bf16x2(f2 - __uint_as_float(hi[1] << 16), f3 - __uint_as_float(hi[1] & 0xffff0000u));
+                            const int vo2 = m0 + i * 16 + pr < p.M ? (pr * p.ldo + 4 * pg) * 2 : OOB;
+                            const int so2 = (m0 + i * 16) * p.ldo * 2 + (nf >> 5) * 128 + (nf & 31) * 2;
+                            __builtin_amdgcn_raw_buffer_store_b64(hi, rsrcO, vo2, so2, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(lo, rsrcO, vo2, so2 + 64, 0);
+                            continue;
+                        }
                         if ((p.flags & FFN_IG_OUT_KV64) && nf >= p.kv64_from) {      // the attention kernels' pre-split K image: [hi(64) | lo(64)] per head
                             const float f0 = __uint_as_float(w[0]), f1 = __uint_as_float(w[1]), f2 = __uint_as_float(w[2]), f3 = __uint_as_float(w[3]);
                             u32x2 hi, lo;

@@ -386,7 +386,7 @@ def linear(x, w, bias=None, *, K=None, out=None, residual=None, rowbias=None, ro
             out = alloc(nb, N, transposed_ld, dtype=odt, device=x.device)
         d.ldo = transposed_ld
     elif out_pair:                                  # split-bf16 only: the result in the pair form the next GEMM reads
-        assert x3 and residual is None and out is None
+        assert x3 and out is None                   # (a residual is added in fp32 before the split)
         flags |= L.IG_OUT_PAIR
         out = _mark_pair(torch.empty(*x.shape[:-1], 2 * n_out, dtype=torch.bfloat16, device=x.device), n_out)
         d.ldo = 2 * n_out

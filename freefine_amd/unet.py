@@ -712,7 +712,8 @@ class HipUNet:
         # --- feed forward (GEGLU fused in the first GEMM's epilogue)
         y = ops.layernorm(h, *t.ln[2], pair=self.x3)
         y = ops.linear(y, t.ff1[0], t.ff1[1], K=C, geglu=True, out_pair=self.x3)
-        h = ops.linear(y, t.ff2[0], t.ff2[1], K=4 * C, residual=h)
+        # (the block's last residual sum feeds proj_out only: split-bf16 mode writes it as the pair rows that GEMM reads, no ffn_split_pair pass)
+        h = ops.linear(y, t.ff2[0], t.ff2[1], K=4 * C, residual=h, out_pair=self.x3 and C % 32 == 0)
         return ops.linear(h, t.proj_out[0], t.proj_out[1], K=C, residual=res0, out=out)
 
     def _run(self, sample, text_kv):

@@ -54,7 +54,8 @@ enum {
     FFN_IG_GEGLU = 1 << 2,         /* N = 2*Nout; 16-column blocks alternate hidden/gate; out = hidden * gelu(gate) */
     FFN_IG_OUT_TRANSPOSED = 1 << 3, /* out[b][n][s], row stride ldo, m = b*rows_per_batch + s (V^T for ffn_attn) */
     FFN_IG_OUT_PAIR = 1 << 4,       /* FFN_BF16X3 only: out is the bf16 PAIR form [M][ldo] of rows of C = ldo/2 columns (layout: FFN_BF16X3 below) -- the A
-                                       operand of the next FFN_BF16X3 GEMM (the GEGLU projection feeding ff.net.2); no residual */
+                                       operand of the next FFN_BF16X3 GEMM (the GEGLU projection feeding ff.net.2; round 6: ff.net.2 + residual feeding proj_out -- bias, row
+                                       bias and the fp32 residual are added before the split; out must not alias the residual) */
     FFN_IG_OUT_GELU = 1 << 5,       /* out = gelu_erf(acc + bias) (+ residual): the MLP of the DINOv2 blocks (dinov2/layers/mlp.py:31-38) */
     FFN_IG_OUT_KV64 = 1 << 7,       /* FFN_BF16X3 only (round 6): the projection writes the attention kernels' PRE-SPLIT K / V^T images itself (what ffn_attn_presplit
                                        produces from an fp32 K / V^T: one fp32 round trip and one HBM-bound pass less per self-attention block).  Row-major output:

@@ -1318,6 +1318,38 @@ def test_x3_kv64_projections_write_the_presplit_images(gpu, B, S, heads, pairA, 
     assert not ops.kv_images_ok(D, S, S, None, 2 ** 31) and not ops.kv_images_ok(40, S, S) and not ops.kv_images_ok(D, 64, 64)
 
 
+@pytest.mark.parametrize("tuned", [False, True])
+@pytest.mark.parametrize("M,C", [(8 * 4096, 320), (384, 320), (12 * 1024, 640), (24 * 256, 1280), (6 * 64, 1280)])
+def test_x3_linear_pair_output_with_residual(gpu, M, C, tuned):
+    """Round 6: the feed-forward's second GEMM (K = 4C, + bias + fp32 residual) writes the block's last residual sum directly as the pair rows the proj_out
+    GEMM reads (FFN_IG_OUT_PAIR beside a residual: ping-pong tile, two-stage tile and the split-K reduce all add the residual in fp32 BEFORE the split).
+    Same kernel with and without the flag (tuner off): bit-equal to ffn_split_pair of the fp32 result.  Tuner on (tile / split-K choice may differ):
+    hi + lo equals the fp32 result to the pair form's resolution."""
+    from freefine_amd import _lib, ops
+    g = torch.Generator().manual_seed(M + C)
+    lib = _lib.load()
+    y = rnd((M, 4 * C), torch.float32, gpu, g)
+    res = rnd((M, C), torch.float32, gpu, g)
+    w = ops.pack_linear(rnd((C, 4 * C), torch.float32, gpu, g, (4 * C) ** -0.5), torch.float32, x3=True)
+    b = rnd((C,), torch.float32, gpu, g)
+    ya = ops.split_pair(y, 4 * C)
+    prev = lib.ffn_igemm_tune_enable(1 if tuned else 0)
+    try:
+        f = ops.linear(ya, w, b, K=4 * C, residual=res)
+        p = ops.linear(ya, w, b, K=4 * C, residual=res, out_pair=True)
+    finally:
+        lib.ffn_igemm_tune_enable(prev)
+    assert p.dtype == torch.bfloat16 and tuple(p.shape) == (M, 2 * C) and ops.pair_width(p) == C
+    if not tuned:
+        assert torch.equal(p.view(torch.int16), ops.split_pair(f, C).view(torch.int16))
+    else:
+        assert relerr(pair_value(p, C), f.double()) < 1e-5
+        assert (pair_value(p, C) - f).abs().max() < 1e-4
+    # and it is what the next GEMM reads: proj_out on the pair rows == proj_out on the fp32 sum
+    w2 = ops.pack_linear(rnd((C, C), torch.float32, gpu, g, C ** -0.5), torch.float32, x3=True)
+    assert relerr(ops.linear(p, w2, None, K=C), ops.linear(f, w2, None, K=C).double()) < 2e-5
+
+
 def test_x3_kv64_rejects_what_it_cannot_write(gpu):
     """the C ABI refuses FFN_IG_OUT_KV64 outside its contract instead of writing a wrong image: not split-bf16, an epilogue with bias-free extras,
     widths that are not whole 64-blocks"""

@@ -1,11 +1,8 @@
 #!/bin/bash
 mkdir -p gpurun_out
-export ONE_MODE=x3
-ONE_B=24 bash tools/pmc.sh r6_x3w_attn_S4096_24rows_2pass_masked attn 4096 320 5 2 > /dev/null
-ONE_B=24 FFN_ATTN_X3W=0 bash tools/pmc.sh r6_x3p_attn_S4096_24rows_2pass_masked attn 4096 320 5 2 > /dev/null
-ONE_B=24 bash tools/pmc.sh r6_x3w_attn_S4096_24rows_1pass attn 4096 320 5 1 > /dev/null
-ONE_B=24 FFN_ATTN_X3W=0 bash tools/pmc.sh r6_x3p_attn_S4096_24rows_1pass attn 4096 320 5 1 > /dev/null
-ONE_B=24 bash tools/pmc.sh r6_x3w_attn_S1024_24rows_2pass_masked attn 1024 640 10 2 > /dev/null
-ONE_B=24 FFN_ATTN_X3W=0 bash tools/pmc.sh r6_x3p_attn_S1024_24rows_2pass_masked attn 1024 640 10 2 > /dev/null
-for f in gpurun_out/pmc_r6_x3*.txt; do echo "== $f"; cat $f; done
-for x in 1 0; do for a in "4096 320 5 2" "4096 320 5 1" "1024 640 10 2" "1024 640 10 1" "256 1280 20 2"; do ONE_B=24 ONE_TIME=50 FFN_ATTN_X3W=$x python tools/one_kernel.py attn $a 2>&1 | grep "us per call" | sed "s/^/X3W=$x /"; done; done | tee gpurun_out/r6_attn_event_times.txt
+timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q -k "pair_output_with_residual or kv64 or pair_producers" 2>&1 | tail -30 | cut -c1-300 | tee gpurun_out/r6_pairres_tests.txt
+timeout 1500 python -m pytest tests/test_unet_gpu.py tests/test_pipeline_gpu.py -m gpu -q -x 2>&1 | tail -8 | cut -c1-300 | tee gpurun_out/r6_unet_pipeline_tests.txt
+for v in 1 0 1; do
+  FFN_KV64=$v timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-fast-modes --no-ref-layout 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('FFN_KV64=$v', d['value'], d['ms_per_step'], d['roofline']['hbm_bound_kernels']['share_of_timed_kernels'])" | tee -a gpurun_out/r6_pairres_bench.txt
+done
+cp gpurun_out/bench_kernel_table.txt gpurun_out/r6_bench_kernel_table_pairres.txt
