@@ -40,6 +40,11 @@ typedef __attribute__((address_space(3))) uint8_t x3w_lds_u8_t;
 #ifndef X3W_SPREAD
 #define X3W_SPREAD 0  // 1: the iteration's LDS-DMA requests ride the vector-free MFMA gaps of its two steps; 0: all at its start (faster: see the header of the key loop)
 #endif
+#ifndef X3W_SUMP1
+#define X3W_SUMP1 0   // 1: the row sums of a unit's probabilities ride the phase-1 gaps of the step that SPLITS them instead of the phase-2 gaps beside their
+                      // exponentials.  Measured SLOWER on one box (profiles/r6_x3w_row_sums_in_phase1_ab.txt: 1461 vs 1412 us two-pass S = 4096, 832 vs 815 one-pass):
+                      // the phase-1 gaps (four split instructions + the fragment reads' issue) have no slack either.  Kept for the A/B only.
+#endif
 #ifndef X3W_ABL
 #define X3W_ABL 0     // timing-only ablations (tools/native/x3w_bench.hip): 1 no softmax / split VALU, 2 no LDS-DMA in the loop, 3 no MFMA
 #endif
@@ -362,14 +367,20 @@ __global__ __launch_bounds__(256) void attn_x3w_kernel(const AttnParams p) {
             else x3w_mma(fr[buf][0], ph[sp][qb], o[db][qb]);
         };
         // phase-1 group g: the six MFMAs of d k-step g beside the split of part g = (s' = g >> 1, qb = g & 1) of cu, four instructions per gap
-        auto p1_group = [&](auto G, auto&& next_reads, const f32x16 (&cu)[2], f32x16 (&nx)[2]) {
+        auto p1_group = [&](auto G, auto&& next_reads, const f32x16 (&cu)[2], f32x16 (&nx)[2], float (&lp)[2][2]) {
             constexpr int g = std::remove_reference_t<decltype(G)>::value, sp = g >> 1, qp = g & 1;
             typedef std::integral_constant<int, g> GT;
             const f32x16& x = cu[qp];
             uint32_t hw[4], lw[4];
             float d0[4], d1[4];
             auto S1 = [&](int i) { hw[i] = pack_bf16x2(x[8 * sp + 2 * i], x[8 * sp + 2 * i + 1]); };
-            auto S2 = [&](int i) { d0[i] = x[8 * sp + 2 * i] - __uint_as_float(hw[i] << 16); d1[i] = x[8 * sp + 2 * i + 1] - __uint_as_float(hw[i] & 0xffff0000u); };
+            auto S2 = [&](int i) {
+                d0[i] = x[8 * sp + 2 * i] - __uint_as_float(hw[i] << 16); d1[i] = x[8 * sp + 2 * i + 1] - __uint_as_float(hw[i] & 0xffff0000u);
+                if (X3W_SUMP1) {                                 // the row sums of cu, two adds per gap, pinned to it (otherwise sunk to the end of the step)
+                    lp[qp][0] += x[8 * sp + 2 * i]; lp[qp][1] += x[8 * sp + 2 * i + 1];
+                    asm volatile("" : "+v"(lp[qp][0]), "+v"(lp[qp][1]));
+                }
+            };
             auto S3 = [&](int i) { lw[i] = pack_bf16x2(d0[i], d1[i]); };
             constexpr bool valu = X3W_ABL != 1;
             next_reads();
@@ -391,9 +402,9 @@ __global__ __launch_bounds__(256) void attn_x3w_kernel(const AttnParams p) {
             constexpr bool doexp = decltype(DOEXP)::value != 0 && X3W_ABL != 1;
             typedef decltype(DB) DBT; typedef decltype(SP) SPT; typedef decltype(BUF) BT;
             auto EX = [&](int idx) { if (doexp && idx >= lo && idx < hi) nx[idx >> 4][idx & 15] = __builtin_amdgcn_exp2f(nx[idx >> 4][idx & 15]); };
-            auto AD = [&](int idx) { if (doexp && idx >= lo && idx < hi) lp[idx >> 4][idx & 1] += nx[idx >> 4][idx & 15]; };
+            auto AD = [&](int idx) { if (!X3W_SUMP1 && doexp && idx >= lo && idx < hi) lp[idx >> 4][idx & 1] += nx[idx >> 4][idx & 15]; };
             // the sums must EXIST at the end of their gap (pure register arithmetic is otherwise sunk to its first use, the end of the step)
-            auto PIN = [&]() { if (doexp) asm volatile("" : "+v"(lp[0][0]), "+v"(lp[0][1]), "+v"(lp[1][0]), "+v"(lp[1][1])); };
+            auto PIN = [&]() { if (doexp && !X3W_SUMP1) asm volatile("" : "+v"(lp[0][0]), "+v"(lp[0][1]), "+v"(lp[1][0]), "+v"(lp[1][1])); };
             next_reads();
             mma_pv(DBT{}, SPT{}, BT{}, I0{}, I0{}); EX(lo); EX(lo + 1); X3W_SB();
             mma_pv(DBT{}, SPT{}, BT{}, I0{}, I1{}); EX(lo + 2); EX(lo + 3); AD(lo); AD(lo + 1); PIN(); X3W_SB();
@@ -436,11 +447,12 @@ __global__ __launch_bounds__(256) void attn_x3w_kernel(const AttnParams p) {
             if (!last) {
                 const uint32_t mb = mask_byte(maddr);
                 if (!kpre) { rd_k(koff, I0{}, I0{}); rd_k(koff, I1{}, I1{}); }
+                if (X3W_SUMP1) lpart[0][0] = lpart[0][1] = lpart[1][0] = lpart[1][1] = 0.f;
                 X3W_SB();
-                p1_group(I0{}, [&]() { rd_k(koff, I2{}, I2{}); }, cu, nx);
-                p1_group(I1{}, [&]() { rd_k(koff, I3{}, I3{}); }, cu, nx);
-                p1_group(I2{}, [&]() { rd_v(voff, I0{}, SV0{}, I0{}); }, cu, nx);
-                p1_group(I3{}, [&]() { rd_v(voff, I0{}, SV1{}, I1{}); }, cu, nx);
+                p1_group(I0{}, [&]() { rd_k(koff, I2{}, I2{}); }, cu, nx, lpart);
+                p1_group(I1{}, [&]() { rd_k(koff, I3{}, I3{}); }, cu, nx, lpart);
+                p1_group(I2{}, [&]() { rd_v(voff, I0{}, SV0{}, I0{}); }, cu, nx, lpart);
+                p1_group(I3{}, [&]() { rd_v(voff, I0{}, SV1{}, I1{}); }, cu, nx, lpart);
                 // the augmenting k-step closes the chains: scores relative to the query's reference, masked keys at -1e30; the third V^T group is requested here
                 rd_v(voff, I1{}, SV0{}, I2{});
                 const u32x4 ka = kaug_of(mb);
@@ -457,15 +469,30 @@ __global__ __launch_bounds__(256) void attn_x3w_kernel(const AttnParams p) {
                 mma_pv(I0{}, I0{}, I0{}, I1{}, I2{}); dmaf(I3{}); X3W_SB();
                 const bool rr = X3W_ABL != 1 && need_reref();
                 if (rr) reref(nx);
-                lpart[0][0] = lpart[0][1] = lpart[1][0] = lpart[1][1] = 0.f;
+                if (!X3W_SUMP1) lpart[0][0] = lpart[0][1] = lpart[1][0] = lpart[1][1] = 0.f;
                 X3W_SB();
                 p2_group(I0{}, I1{}, I1{}, I0{}, std::integral_constant<int, 11>{}, I1{}, [&]() { rd_v(voff, I1{}, SV1{}, I3{}); }, nx, lpart);
                 p2_group(I1{}, I0{}, I2{}, std::integral_constant<int, 11>{}, std::integral_constant<int, 22>{}, I1{}, [&]() { if (knext) rd_k(koff_next, I0{}, I0{}); }, nx, lpart);
                 p2_group(I1{}, I1{}, I3{}, std::integral_constant<int, 22>{}, std::integral_constant<int, 32>{}, I1{}, [&]() { if (knext) rd_k(koff_next, I1{}, I1{}); }, nx, lpart);
+                if (X3W_SUMP1) {                                // lpart = the sums of cu (this unit, at the OLD reference): in before the move
+                    lacc[0] += lpart[0][0] + lpart[0][1];
+                    lacc[1] += lpart[1][0] + lpart[1][1];
+                }
                 if (rr) rescale();                              // O and the sums through this unit are complete at the old reference: now they move
-                lacc[0] += lpart[0][0] + lpart[0][1];
-                lacc[1] += lpart[1][0] + lpart[1][1];
+                if (!X3W_SUMP1) {                               // lpart = the sums of nx (the next unit, exponentiated at the NEW reference)
+                    lacc[0] += lpart[0][0] + lpart[0][1];
+                    lacc[1] += lpart[1][0] + lpart[1][1];
+                }
             } else {
+                if (X3W_SUMP1) {
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) {
+                        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 16; i += 2) { a0 += cu[qb][i]; a1 += cu[qb][i + 1]; }
+                        lacc[qb] += a0 + a1;
+                    }
+                }
                 rd_v(voff, I0{}, SV0{}, I0{}); rd_v(voff, I0{}, SV1{}, I1{}); rd_v(voff, I1{}, SV0{}, I2{}); rd_v(voff, I1{}, SV1{}, I3{});
                 split_part(I0{}, cu); split_part(I1{}, cu); split_part(I2{}, cu); split_part(I3{}, cu);
                 X3W_SB();
@@ -492,8 +519,10 @@ __global__ __launch_bounds__(256) void attn_x3w_kernel(const AttnParams p) {
             if (X3W_ABL != 1 && need_reref()) { reref(s0); rescale(); }
             lpart[0][0] = lpart[0][1] = lpart[1][0] = lpart[1][1] = 0.f;
             expsum(I0{}, std::integral_constant<int, 32>{}, s0);
-            lacc[0] += lpart[0][0] + lpart[0][1];
-            lacc[1] += lpart[1][0] + lpart[1][1];
+            if (!X3W_SUMP1) {                                   // (X3W_SUMP1: unit 0's sums are taken by the step that splits it, like every unit's)
+                lacc[0] += lpart[0][0] + lpart[0][1];
+                lacc[1] += lpart[1][0] + lpart[1][1];
+            }
         }
         if (AHEAD == 1) {
             lds_done();
