@@ -1,11 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
-R=$GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/mb; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/mb -- python3 $R/tools/membound_x3.py 72 > /dev/null 2>&1
-f=$(ls /tmp/mb/*/*kernel_stats.csv | head -1)
-python3 - "$f" <<'PY' | tee $R/gpurun_out/r6_membound_kernel_stats.txt
-import csv, sys
-for r in csv.DictReader(open(sys.argv[1])):
-    print(f"{r['Name'][:100]:100s} calls {r['Calls']:>6s} avg_us {float(r['AverageNs'])/1e3:9.1f} min_us {float(r['MinNs'])/1e3:9.1f} max_us {float(r['MaxNs'])/1e3:9.1f}")
-PY
+for c in 6 10; do
+timeout 900 python bench.py --batch 1 --concurrent $c --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-fast-modes --no-ref-layout 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('batch 1 x $c streams:', d['value'], 'images/s', d['ms_per_step'], 'ms per step'); r=d['roofline']; print(r['kernel'], r['frac'], r['share_of_timed_kernels']); [print(k['kernel'], k.get('frac'), k['share_of_timed_kernels']) for k in r['next_kernels']]" | tee -a gpurun_out/r6_one_image_layout.txt
+cp gpurun_out/bench_kernel_table.txt gpurun_out/r6_one_image_kernel_table_c$c.txt
+done
