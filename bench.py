@@ -26,7 +26,7 @@ batch of edits, so every step pays for its prompts.
 Extra objects on the JSON line:
   parity        this run's own check: the headline mode's latent trajectory against the f32 mode's over the FULL schedule (absolute L-inf,
                 `passes`), beside the names of the gates that pin both modes to the reference / oracle.
-  fast_modes    bf16 (and with --fp8-leg the e4m3-convolution variant): throughput by the same protocol (at --extra-batch images per UNet batch, like
+  fast_modes    bf16 (and with --fp8-leg the e4m3-convolution variant): throughput by the same protocol at the headline's own layout (--batch images per UNet batch; the f32 leg at --extra-batch, like
                 parity.f32_mode: each record names its batch x streams) + the deviation that disqualifies it.
   roofline      the dominant kernel (largest total time of an eagerly executed, HIP-event-timed image in this very process):
                 achieved = algorithmic FLOPs per launch / average launch duration; peak = dense MFMA peak of the dtype.
@@ -210,14 +210,16 @@ def deviation(traj, ref):
             "relative_to_latent_abs_max": float(f"{d.max().item() / amax:.3e}")}
 
 
-def timed_mode(args, device, mode, steps, fp8=False, base=7000):
+def timed_mode(args, device, mode, steps, fp8=False, base=7000, batch=None):
     """throughput of another arithmetic mode by the headline's protocol: --extra-batch images per UNet batch, same number of HIP streams, one warm-up
     pass per stream (tuning, graph capture), then `steps` timed steps between synchronisations.  Returns (record, model)."""
     import copy
     import threading
     a = copy.copy(args)
     a.dtype, a.fp8_conv = mode, fp8
-    a.batch = min(args.batch, args.extra_batch)       # side legs: at most --extra-batch images per UNet batch (the record says which), to bound the run time
+    # side legs: the f32 leg at most --extra-batch images per UNet batch (the record says which), to bound the run time; the bf16 fast mode at the
+    # headline's own layout (batch = args.batch), so that the two throughputs are like for like
+    a.batch = batch if batch is not None else min(args.batch, args.extra_batch)
     m = build_model(a, device, 0, 1)
     models = [m] + [add_sibling(m) for _ in range(args.concurrent - 1)]
     streams = [torch.cuda.Stream(device=device) for _ in models]
@@ -282,7 +284,7 @@ def fast_modes_leg(args, device):
     out = {}
     modes = [("bf16", False)] + ([("bf16+fp8_conv", True)] if args.fp8_leg else [])
     for name, fp8 in modes:
-        rec, m = timed_mode(args, device, "bf16", args.extra_steps, fp8=fp8, base=8000)
+        rec, m = timed_mode(args, device, "bf16", args.extra_steps, fp8=fp8, base=8000, batch=args.batch)
         if _F32_TRAJ is not None:
             dev = deviation(one_image_trajectory(m, args), _F32_TRAJ)
             dev["passes"] = bool(dev["max_over_steps"] <= 1e-3)
@@ -494,6 +496,7 @@ def main():
         value = world * args.steps * args.concurrent * args.batch / dt
         line = {
             "metric": "edited images/sec/GPU @512px 50-step DDIM", "value": round(value, 4), "unit": "images/s", "n_gpus": world,
+            "value_scope": "whole job: images/s summed over the n_gpus ranks (max-over-ranks time); per GPU = value / n_gpus", "value_per_gpu": round(value / world, 4),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"SD-2.1-base topology ({args.model}) 512x512 FreeFine_generation edit, {args.num_step}-step DDIM schedule "
