@@ -63,7 +63,8 @@ for (hw, K, N, kind) in [(64, 320, 640, "qk"), (64, 320, 320, "res"), (64, 320, 
     w = rnd(N, K, scale=K ** -0.5)
     if kind == "geglu":
         wp, bp = ops.pack_geglu(w, torch.zeros(N, device=dev), torch.float32, True)
-        fn = lambda: ops.linear(x, wp, bp, K=K, geglu=True)
+        fn = lambda: ops.linear(x, wp, bp, K=K, geglu=True, out_pair=True)       # the pipeline's form: pair rows for ff.net.2 (without out_pair the launch
+                                                                                 # takes the generic two-stage tile: the 0.25-0.32 of the round-5 table)
     elif kind == "res":
         wp = ops.pack_linear(w, torch.float32, True)
         r = rnd(B, hw * hw, N)
@@ -74,3 +75,13 @@ for (hw, K, N, kind) in [(64, 320, 640, "qk"), (64, 320, 320, "res"), (64, 320, 
         fn = lambda: ops.linear(x, wp, None, K=K)
     us = timeit(fn)
     report(f"x3 gemm {kind:5s} M={M} K={K} N={N}", us, 2.0 * M * N * K)
+    if kind == "qk":        # round 6: the k half written as the attention kernels' pre-split image, and the V^T projection beside it
+        us = timeit(lambda: ops.linear(x, wp, None, K=K, kv64_from=N // 2))
+        report(f"x3 gemm qk    M={M} K={K} N={N} k half as [hi|lo] image", us, 2.0 * M * N * K)
+        wv = ops.pack_linear(rnd(K, K, scale=K ** -0.5), torch.float32, True)
+        for img in (None, 0):
+            us = timeit(lambda: ops.linear(x, wv, None, K=K, rows_per_batch=hw * hw, transposed_ld=hw * hw, kv64_from=img))
+            report(f"x3 gemm v^T   M={M} K={K} N={K}{' [hi|lo] image' if img is not None else ''}", us, 2.0 * M * K * K)
+    if kind == "res" and N * 4 == K:      # ff.net.2: round 6 writes the residual sum as pair rows for proj_out
+        us = timeit(lambda: ops.linear(x, wp, bb, K=K, residual=r, out_pair=True))
+        report(f"x3 gemm res   M={M} K={K} N={N} -> pair rows", us, 2.0 * M * N * K)
