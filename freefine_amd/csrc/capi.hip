@@ -255,22 +255,25 @@ extern "C" int ffn_attn_variant(int dtype, int D, int* dp, int* qf) {
 // runs the N = 320 convs at 850-1000 TFLOP/s where 128x128 -- 17% of its third column tile wasted -- gives 690-760; 256x256
 // reaches 1190 on N = 1280 but loses 20% on N = 640).  So the first time a problem shape is seen outside stream capture, the
 // few plausible configurations are timed on the caller's stream with the caller's buffers and the winner is cached.
-enum { CFG_64x64, CFG_128x64, CFG_128x128_8, CFG_128x128_16, CFG_256x128, CFG_256x256, CFG_128x320, CFG_128x160, CFG_192x320, CFG_H_128x320, CFG_H_256x128, CFG_H_256x256, CFG_H_128x128, CFG_PP_256x320, CFG_PP_256x256, CFG_PP_192x320, CFG_PP_192x256, CFG_COUNT };
+enum { CFG_64x64, CFG_128x64, CFG_128x128_8, CFG_128x128_16, CFG_256x128, CFG_256x256, CFG_128x320, CFG_128x160, CFG_192x320, CFG_H_128x320, CFG_H_256x128, CFG_H_256x256, CFG_H_128x128, CFG_PP_256x320, CFG_PP_256x256, CFG_PP_192x320, CFG_PP_192x256, CFG_PP_256x128, CFG_COUNT };
 struct IgCfgInfo { int bm, bn, nwm, nwn; };
 static const IgCfgInfo kCfg[CFG_COUNT] = {{64, 64, 2, 2}, {128, 64, 4, 2}, {128, 128, 2, 4}, {128, 128, 4, 4},
                                           {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 320, 4, 4}, {128, 160, 4, 2}, {192, 320, 3, 4},
                                           {128, 320, 4, 4}, {256, 128, 4, 4}, {256, 256, 4, 4}, {128, 128, 4, 4},    // halo kernel (3x3 stride-1 convs)
-                                          {256, 320, 2, 4}, {256, 256, 2, 4}, {192, 320, 2, 4}, {192, 256, 2, 4}};     // ping-pong kernel (igemm_p8.h)
+                                          {256, 320, 2, 4}, {256, 256, 2, 4}, {192, 320, 2, 4}, {192, 256, 2, 4},      // ping-pong kernel (igemm_p8.h)
+                                          {256, 128, 2, 4}};    // its 128-column tile: split-bf16 3x3 convolutions to N % 128 == 0 channels (the VAE's 128-channel layers)
 struct IgChoice { int cfg, splitk; };
 struct TunedEntry { IgChoice ch; bool validated; };   // imported entries (file / another rank) are checked against the problem at first use
 
 static bool is_halo_cfg(int cfg) { return cfg == CFG_H_128x320 || cfg == CFG_H_256x128 || cfg == CFG_H_256x256 || cfg == CFG_H_128x128; }
-static bool is_pp_cfg(int cfg) { return cfg >= CFG_PP_256x320 && cfg <= CFG_PP_192x256; }
+static bool is_pp_cfg(int cfg) { return cfg >= CFG_PP_256x320 && cfg <= CFG_PP_256x128; }
 // whether the ping-pong kernel (igemm_p8.h) handles this problem on a bm x bn tile: its restrictions are listed in that header
 static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn, int splitk = 1) {
     const long lim = (1l << 31) - 4096;
     // K tiles of the kernel: 64 bf16 elements; split-bf16 (d.K = the virtual 3 K): one 128-byte block [hi(32) | lo(32)] = 32 real elements
     const int nkt = d.x3 ? d.K / 96 : d.K / 64;
+    // the 128-column tile exists for unsplit split-bf16 3x3 convolutions with a plain / residual epilogue only
+    if (bn == 128 && (bm != 256 || !d.x3 || d.conv != 1 || splitk > 1 || (d.flags & (FFN_IG_GEGLU | FFN_IG_OUT_PAIR | FFN_IG_OUT_KV64 | FFN_IG_OUT_TRANSPOSED)))) return false;
     if (d.x3) {
         if (d.x3 != 2 || d.K % 96 != 0 || d.a_lo != 32) return false;             // blocked operands only
     } else if (d.K % 64 != 0) return false;
@@ -364,7 +367,8 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
         case CFG_PP_256x320:
         case CFG_PP_256x256:
         case CFG_PP_192x320:
-        case CFG_PP_192x256: {
+        case CFG_PP_192x256:
+        case CFG_PP_256x128: {
             if (!pp_ok(d, c.bm, c.bn, ch.splitk)) return fail(FFN_EINVAL, "igemm: ping-pong kernel not applicable");
             const int pplds = 2 * (c.bm + c.bn) * 128 + 12288;
             const int nt = ((d.M + c.bm - 1) / c.bm) * (d.N / c.bn) * ch.splitk;
@@ -398,6 +402,15 @@ static int launch_bf16_cfg(hipStream_t s, const ffn_igemm_desc& d, IgChoice ch) 
         if ((rc = set_lds(kern, pplds))) return rc;                                        \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pplds, s, d, ch.splitk);           \
     } while (0)
+            if (c.bn == 128) {                 // (pp_ok: split-bf16 3x3 convolution, unsplit)
+                if constexpr (X3 && AMODE == AMODE_CONV3) {
+                    if (d.residual) FFN_PP_LAUNCH(256, 128, true, false);
+                    else FFN_PP_LAUNCH(256, 128, false, false);
+                    return check_launch("igemm(ping-pong, 256 x 128)");
+                } else {
+                    return fail(FFN_EINVAL, "igemm: the 256 x 128 ping-pong tile is built for split-bf16 3x3 convolutions");
+                }
+            }
             if (ch.splitk > 1) {
                 if (c.bm == 256 && c.bn == 320) FFN_PP_SPLIT(256, 320);
                 else if (c.bm == 256) FFN_PP_SPLIT(256, 256);
@@ -516,6 +529,7 @@ static IgChoice heuristic_choice(const ffn_igemm_desc& d) {
             }
             if (best >= 0) return IgChoice{bn == 320 ? (bh == 256 ? CFG_PP_256x320 : CFG_PP_192x320) : (bh == 256 ? CFG_PP_256x256 : CFG_PP_192x256), 1};
         }
+        if (d.N % 128 == 0 && pp_ok(d, 256, 128) && (long)((d.M + 255) / 256) * (d.N / 128) * 4 >= (long)device_cus() * 3) return IgChoice{CFG_PP_256x128, 1};
     }
     int bm, bn, sk, ns, nw;
     igemm_plan_for(FFN_BF16, d, &bm, &bn, &sk);
@@ -548,7 +562,7 @@ static int candidates_for(const ffn_igemm_desc& d, IgChoice* out, int cap) {
             const long pt = (long)((d.M + c.bm - 1) / c.bm) * (d.N / (c.bn > 0 ? c.bn : 1));
             if (d.splitk <= 1 && pp_ok(d, c.bm, c.bn) && n < cap) out[n++] = IgChoice{cfg, 1};
             static const int split_below = [] { const char* e = getenv("FFN_PP_SPLIT_BELOW"); return e ? atoi(e) : 160; }();      // unsplit tile counts below this get split-K candidates
-            if (d.splitk != 1 && pt > 0 && pt < split_below && d.N % c.bn == 0) {
+            if (cfg != CFG_PP_256x128 && d.splitk != 1 && pt > 0 && pt < split_below && d.N % c.bn == 0) {
                 const int nkt = d.x3 ? d.K / 96 : d.K / 64;
                 int added = 0;
                 for (int sgo = (int)((384 + pt - 1) / pt); sgo >= 2 && added < 2; --sgo) {

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     constexpr int FM = HM / 16;             // 16-row fragments per wave (8 or 6), FH of them per phase
     constexpr int FH = FM / 2;
     constexpr int NA = BM / 64;             // A pieces per wave and K tile (4 or 3): 2 requested in phase 3, NA - 2 in phase 4
-    constexpr int FN = BN / 64;             // 16-column fragments per wave (4 or 5)
+    constexpr int FN = BN / 64;             // 16-column fragments per wave (4 or 5; 2 on the 256 x 128 tile)
     constexpr int WN = BN / 4;              // columns per wave
     constexpr int ABYTES = BM * 128, BBYTES = BN * 128, BUF = ABYTES + BBYTES;
     constexpr int CV = 2 * BUF;             // column vectors: per wave [bias | row bias of the first image | of the next image] x 128 floats
@@ -126,7 +126,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IgemmParams p, int 
     constexpr int NST = (SPLIT || TRANS || X3) ? FH * FN : (GEGLU ? FH * FN / 2 : FH * ((FN + 1) / 2));
     constexpr int OSZ = (X3 && !GEGLU) ? 4 : 2;         // bytes per output / residual element
     constexpr int OOB = (int)0x80000000;
-    static_assert((BM == 256 || BM == 192) && (BN == 256 || BN == 320), "tiles built for this kernel");
+    // (BN = 128, round 6: the VAE's 128-channel 3x3 convolutions in split-bf16 mode -- two column fragments per wave, launched by capi.hip for X3 convolutions only)
+    static_assert((BM == 256 || BM == 192) && (BN == 256 || BN == 320 || (BN == 128 && BM == 256 && X3 && AMODE == AMODE_CONV3 && !GEGLU && !SPLIT && !TRANS)), "tiles built for this kernel");
     static_assert(!GEGLU || FN % 2 == 0, "GEGLU pairs hidden / gate column blocks inside a wave");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];

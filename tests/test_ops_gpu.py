@@ -857,8 +857,8 @@ def test_x3_conv3x3(gpu, cfg):
 
 
 def test_x3_every_configuration_and_determinism(gpu):
-    """every split-bf16 configuration forced in turn (generic 64x64 / 128x64 / 128x128 tiles and the four ping-pong tiles, unsplit and
-    split-K), ragged M, GEGLU, residual; bit-repeatability of the pipelined kernel in this mode."""
+    """every split-bf16 configuration forced in turn (generic 64x64 / 128x64 / 128x128 tiles, the four ping-pong tiles, unsplit and
+    split-K, and the 256 x 128 ping-pong tile of the 128-channel convolutions), ragged M, GEGLU, residual; bit-repeatability of the pipelined kernel in this mode."""
     from freefine_amd import _lib as L
     from freefine_amd import ops
     lib = L.load()
@@ -888,6 +888,15 @@ def test_x3_every_configuration_and_determinism(gpu):
             for sk in (0, 12):
                 out = ops.conv3x3(x, ops.pack_conv3x3(w, dt, x3=True), b, B, H, H, Cin, rowbias=rb, residual=r, splitk=sk)
                 assert relerr(out, ref) < X3_TOL, (cfg, "conv", sk)
+            # Cout = 128 (the VAE's 128-channel layers): round 6's 256 x 128 ping-pong tile where forced, the generic tiles otherwise; with and without residual
+            for Cin3 in (128, 256):
+                B3, H3, Cout3 = 3, 32, 128
+                x3_, w3 = rnd((B3, H3 * H3, Cin3), dt, gpu, g), rnd((Cout3, Cin3, 3, 3), dt, gpu, g, (9 * Cin3) ** -0.5)
+                b3, r3 = rnd((Cout3,), dt, gpu, g), rnd((B3, H3 * H3, Cout3), dt, gpu, g)
+                ref3 = F.conv2d(x3_.double().reshape(B3, H3, H3, Cin3).permute(0, 3, 1, 2), w3.double(), b3.double(), padding=1).permute(0, 2, 3, 1).reshape(B3, H3 * H3, Cout3)
+                wp3 = ops.pack_conv3x3(w3, dt, x3=True)
+                assert relerr(ops.conv3x3(x3_, wp3, b3, B3, H3, H3, Cin3), ref3) < X3_TOL, (cfg, "conv N=128", Cin3)
+                assert relerr(ops.conv3x3(x3_, wp3, b3, B3, H3, H3, Cin3, residual=r3), ref3 + r3.double()) < X3_TOL, (cfg, "conv N=128 + res", Cin3)
             # Cin = 96: 27 stages of 32 (odd), forced split-K on the chunk-major walk
             Cin2 = 96
             x2, w2 = rnd((B, H * H, Cin2), dt, gpu, g), rnd((Cout, Cin2, 3, 3), dt, gpu, g, (9 * Cin2) ** -0.5)
