@@ -103,6 +103,7 @@ SYMBOLS = {
     "ffn_gn_stats": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "ffn_gn_apply": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "ffn_groupnorm": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "ffn_groupnorm_pair_raw": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "ffn_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f]),
     "ffn_layernorm_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f]),
     "ffn_softmax_rows": (_i, [_vp, _i, _vp, _vp, _l, _i, _f]),

@@ -1381,6 +1381,19 @@ extern "C" int ffn_groupnorm(void* stream, int dtype, const void* x, void* y, co
     if (rc) return rc;
     return ffn_gn_apply(stream, dtype, x, y, scale, shift, B, HW, C, silu | (pair ? FFN_NORM_OUT_PAIR : 0));
 }
+extern "C" int ffn_groupnorm_pair_raw(void* stream, const void* x, void* y, void* yraw, const float* gamma, const float* beta, int B, int HW, int C, int G,
+                                      float eps, int silu, float* partial_ws, float* scale, float* shift) {
+    REQUIRE(x && y && yraw && gamma && beta && partial_ws && scale && shift, "groupnorm_pair_raw: null pointer (the workspace is always needed)");
+    REQUIRE(C % 8 == 0 && C % G == 0 && (C / G) % 2 == 0 && aligned16(x) && aligned16(y) && aligned16(yraw), "groupnorm_pair_raw: bad arguments (C=%d, G=%d)", C, G);
+    REQUIRE(y != yraw && yraw != x && y != x, "groupnorm_pair_raw: x, y and yraw must be distinct buffers");
+    int rc = ffn_gn_stats(stream, FFN_F32, x, gamma, beta, B, HW, C, G, eps, partial_ws, scale, shift);
+    if (rc) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long n8 = (long)B * HW * (C / 8);
+    if (silu & FFN_NORM_SILU) LAUNCH((gn_apply_pair8_kernel<true, true>), dim3(grid_for(n8)), dim3(256), 0, s, (const float*)x, (bf16*)y, scale, shift, n8, HW, C, (bf16*)yraw);
+    else LAUNCH((gn_apply_pair8_kernel<false, true>), dim3(grid_for(n8)), dim3(256), 0, s, (const float*)x, (bf16*)y, scale, shift, n8, HW, C, (bf16*)yraw);
+    return check_launch("gn_apply(pair + raw pair)");
+}
 extern "C" int ffn_groupnorm_f8(void* stream, const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int Cp, int G,
                                 float eps, int silu, float qscale, float* partial_ws, float* scale, float* shift) {
     REQUIRE(x && y && gamma && beta && partial_ws && scale && shift, "groupnorm_f8: null pointer (the workspace is always needed)");

@@ -154,9 +154,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 // expf + an IEEE division (~30 instructions per value: the kernel was VALU-bound, 25 % slower per byte than the statistics pass).  The pair form
 // carries 16-17 significant bits, so SiLU is x * rcp(1 + exp2(-x log2 e)) here (v_exp_f32 / v_rcp_f32: ~1 ulp each, 2e-7 relative).
 // C % 8 == 0 (a thread's 8 channels never straddle a 32-column block of the blocked layout).
-template <bool SILU>
+// RAW (round 6, ffn_groupnorm_pair_raw): the same pass also writes the pair form of x ITSELF to yraw -- the operand of the ResBlock's 1x1 shortcut GEMM, which
+// otherwise costs a ffn_split_pair pass (a second read of x) beside this one.
+template <bool SILU, bool RAW = false>
 __global__ __launch_bounds__(256) void gn_apply_pair8_kernel(const float* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ scale,
-                                                             const float* __restrict__ shift, long n8_total, int HW, int C) {
+                                                             const float* __restrict__ shift, long n8_total, int HW, int C, bf16* __restrict__ yraw = nullptr) {
     const int cch = C / 8;
     const int lo_off = pair_lo(C);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8_total; i += (long)gridDim.x * 256) {
@@ -185,6 +187,17 @@ __global__ __launch_bounds__(256) void gn_apply_pair8_kernel(const float* __rest
         bf16* q = y + pix * 2 * C + pair_pos(c, C);
         *reinterpret_cast<u32x4*>(q) = hi;
         *reinterpret_cast<u32x4*>(q + lo_off) = lo;
+        if (RAW) {
+            const float r[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                hi[w] = pack_bf16x2(r[2 * w], r[2 * w + 1]);
+                lo[w] = pack_bf16x2(r[2 * w] - __uint_as_float(hi[w] << 16), r[2 * w + 1] - __uint_as_float(hi[w] & 0xffff0000u));
+            }
+            bf16* qr = yraw + pix * 2 * C + pair_pos(c, C);
+            *reinterpret_cast<u32x4*>(qr) = hi;
+            *reinterpret_cast<u32x4*>(qr + lo_off) = lo;
+        }
     }
 }
 

@@ -87,6 +87,7 @@ def _igemm_name(lib, dcode, d):
 # weight packing (host side, once at load time)
 # ---------------------------------------------------------------------------------------------------------------
 _GN_CHUNK_MB = float(os.environ.get("FFN_GN_CHUNK_MB", "0"))           # GroupNorm row chunks (MiB of input per chunk; 0 = whole batch at once)
+_GN_RAW = os.environ.get("FFN_GN_RAW", "1") != "0"                     # ResBlock norm1 also writes the pair rows of its input for the 1x1 shortcut GEMM (0: separate ffn_split_pair pass)
 _KV64 = os.environ.get("FFN_KV64", "1") != "0"                         # self-attention K / V^T projections write the pre-split images themselves (0: fp32 + ffn_attn_presplit)
 _ATTN_PRESPLIT = os.environ.get("FFN_ATTN_PRESPLIT", "1") != "0"      # split-bf16 self attention: pre-split K / V^T once per call (0: split inside the kernel's key loop)
 
@@ -640,6 +641,26 @@ def groupnorm(x, gamma, beta, G, eps, silu=False, out=None, ws=None, pair=False)
         name = f"gn_fused_kernel<{_tname(x)}>" if partial is None else f"gn_partial+gn_finalize+gn_apply<{_tname(x)}>"
         L.check(_timed(name, 0.0, 2.0 * x.numel() * x.element_size(), call), "ffn_groupnorm")
     return out
+
+
+def groupnorm_pair_raw(x, gamma, beta, G, eps, silu=False, ws=None):
+    """split-bf16 mode, ResBlock with a 1x1 shortcut: (pair rows of act(GroupNorm(x)), pair rows of x itself) from ONE apply pass over x (ffn_groupnorm_pair_raw) --
+    the second is what split_pair(x) would give, bit for bit.  Shapes the one-launch fused GroupNorm takes (small tensors) keep that kernel + a split_pair pass."""
+    lib = L.load()
+    B, HW, Cc = x.shape
+    if not _GN_RAW or Cc % 8 != 0 or lib.ffn_gn_fused(B, HW, Cc, G) or not x.is_contiguous():
+        return groupnorm(x, gamma, beta, G, eps, silu=silu, pair=True, ws=ws), split_pair(x, Cc)
+    assert x.dtype == torch.float32
+    y = _mark_pair(torch.empty(B, HW, 2 * Cc, dtype=torch.bfloat16, device=x.device), Cc)
+    yr = _mark_pair(torch.empty(B, HW, 2 * Cc, dtype=torch.bfloat16, device=x.device), Cc)
+    partial, scale, shift = ws if ws is not None else gn_workspace(B, HW, Cc, x.device)
+    call = lambda: lib.ffn_groupnorm_pair_raw(_stream(), x.data_ptr(), y.data_ptr(), yr.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B, HW, Cc, G, eps,
+                                              L.NORM_SILU if silu else 0, _p(partial), _p(scale), _p(shift))
+    if _PROF is None:
+        L.check(call(), "ffn_groupnorm_pair_raw")
+    else:       # algorithmic bytes: one read + two writes
+        L.check(_timed("gn_partial+gn_finalize+gn_apply<float> (+ raw pair)", 0.0, 3.0 * x.numel() * x.element_size(), call), "ffn_groupnorm_pair_raw")
+    return y, yr
 
 
 def layernorm(x, gamma, beta, eps=1e-5, out=None, pair=False):

@@ -597,7 +597,11 @@ class HipUNet:
 
     def _resblock(self, r, x, B, H, W, temb_all, out=None):
         cin = x.shape[-1]
-        h = self._gn_conv_in(x, r.n1, r.c1[0])
+        if r.sc is not None and self.x3 and not ops.is_f8(r.c1[0]) and ops.pair_width(x) is None and x.dtype == torch.float32:
+            # split-bf16, ResBlock with a 1x1 shortcut: norm1's apply pass also writes the pair rows of x the shortcut GEMM reads (no ffn_split_pair pass)
+            h, x = ops.groupnorm_pair_raw(x, r.n1[0], r.n1[1], self.cfg.norm_num_groups, self.cfg.norm_eps, silu=True)
+        else:
+            h = self._gn_conv_in(x, r.n1, r.c1[0])
         rb = temb_all[:, r.temb_off:r.temb_off + r.cout]
         h = ops.conv3x3(h, r.c1[0], r.c1[1], B, H, W, cin, rowbias=rb, rowbias_ld=temb_all.shape[1])
         h = self._gn_conv_in(h, r.n2, r.c2[0])

@@ -263,6 +263,12 @@ int ffn_gn_apply(void* stream, int dtype, const void* x, void* y, const float* s
  * GroupNorm at 64x64 latents), else ffn_gn_stats + ffn_gn_apply (workspace pointers may be NULL in the fused case). */
 int ffn_groupnorm(void* stream, int dtype, const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int G,
                   float eps, int silu, float* partial_ws, float* scale, float* shift);
+/* round 6: GroupNorm (three-launch form, fp32 x) whose apply pass writes BOTH pair tensors a ResBlock with a 1x1 shortcut reads: y = pair(act(GN(x))) for conv1
+ * and yraw = pair(x) for the shortcut GEMM (what ffn_split_pair(x) would produce, bit for bit) -- x is read once less.  C % 8 == 0; the workspace is required
+ * (also for shapes ffn_gn_fused() would take in one launch); `silu`: FFN_NORM_SILU or 0.  Reference: the norm1 / conv_shortcut inputs of diffusers' ResnetBlock2D
+ * (in-tree copy /root/reference/evaluation/DragonDiffusion/src/unet/resnet_2d.py:110). */
+int ffn_groupnorm_pair_raw(void* stream, const void* x, void* y_pair, void* yraw_pair, const float* gamma, const float* beta, int B, int HW, int C, int G,
+                           float eps, int silu, float* partial_ws, float* scale, float* shift);
 int ffn_layernorm(void* stream, int dtype, const void* x, void* y, const float* gamma, const float* beta, int M, int C,
                   float eps);
 int ffn_layernorm_pair(void* stream, const float* x, void* y, const float* gamma, const float* beta, int M, int C, float eps);

@@ -1359,6 +1359,24 @@ def test_x3_linear_pair_output_with_residual(gpu, M, C, tuned):
     assert relerr(ops.linear(p, w2, None, K=C), ops.linear(f, w2, None, K=C).double()) < 2e-5
 
 
+@pytest.mark.parametrize("B,HW,C,silu", [(2, 4096, 640, True), (3, 1024, 1920, True), (2, 4096, 320, False), (2, 64, 1280, True), (1, 256, 2560, True)])
+def test_groupnorm_pair_raw_writes_both_operands(gpu, B, HW, C, silu):
+    """ffn_groupnorm_pair_raw (round 6): norm1 of a ResBlock with a 1x1 shortcut writes, from one apply pass, the pair rows of SiLU(GroupNorm(x)) (conv1's operand) and
+    the pair rows of x itself (the shortcut GEMM's operand).  Both BIT FOR BIT what the separate launches give (ffn_groupnorm(..., FFN_NORM_OUT_PAIR) and
+    ffn_split_pair); small tensors (the fused one-launch GroupNorm's shapes) keep the separate launches behind the same call."""
+    from freefine_amd import ops
+    g = torch.Generator().manual_seed(B * HW + C)
+    x = rnd((B, HW, C), torch.float32, gpu, g)
+    ga, be = torch.randn(C, generator=g).to(gpu), torch.randn(C, generator=g).to(gpu)
+    y, yr = ops.groupnorm_pair_raw(x, ga, be, 32, 1e-5, silu=silu)
+    assert ops.pair_width(y) == C and ops.pair_width(yr) == C and y.dtype == torch.bfloat16 and tuple(yr.shape) == (B, HW, 2 * C)
+    assert torch.equal(y.view(torch.int16), ops.groupnorm(x, ga, be, 32, 1e-5, silu=silu, pair=True).view(torch.int16))
+    assert torch.equal(yr.view(torch.int16), ops.split_pair(x, C).view(torch.int16))
+    # and the shortcut GEMM reads it: same result as from the fp32 tensor
+    w = ops.pack_linear(rnd((320, C), torch.float32, gpu, g, C ** -0.5), torch.float32, x3=True)
+    assert torch.equal(ops.linear(yr, w, None, K=C, splitk=1), ops.linear(x, w, None, K=C, splitk=1))
+
+
 def test_x3_kv64_rejects_what_it_cannot_write(gpu):
     """the C ABI refuses FFN_IG_OUT_KV64 outside its contract instead of writing a wrong image: not split-bf16, an epilogue with bias-free extras,
     widths that are not whole 64-blocks"""
