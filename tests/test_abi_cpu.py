@@ -106,3 +106,43 @@ def test_legacy_vae_attention_keys_are_renamed_and_bad_checkpoints_fail_clearly(
     broken.pop("decoder.conv_out.bias")
     with pytest.raises(ValueError, match="decoder.conv_out.bias"):
         validate_state_dict(broken, shapes, "vae")
+
+
+def test_kv64_contract_is_checked_before_any_launch():
+    """FFN_IG_OUT_KV64 (round 6): ffn_igemm validates the image-writing epilogue's contract on the host -- wrong arithmetic mode, a boundary that is not a whole
+    64-column block, a transposed row stride that is not whole blocks, a residual beside it -- and reports -EINVAL with a message naming the flag (no GPU needed:
+    nothing is launched)."""
+    import ctypes
+    from freefine_amd import _lib
+    lib = _lib.load()
+
+    def desc(**kw):
+        d = _lib.IgemmDesc()
+        d.A = d.W = d.out = 0x10000                   # never dereferenced: validation fails first
+        d.M, d.N, d.K, d.Kpad = 4096, 640, 320, 640
+        d.lda, d.ldo, d.x3, d.a_lo = 640, 640, 2, 32
+        d.rows_per_batch, d.alpha, d.splitk = 4096, 1.0, 1
+        d.flags, d.kv64_from = _lib.IG_OUT_KV64, 320
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+    for dtype, d in ((_lib.FFN_BF16, desc()),                                           # not split-bf16
+                     (_lib.FFN_BF16X3, desc(kv64_from=352)),                             # not a 64-column boundary
+                     (_lib.FFN_BF16X3, desc(residual=0x20000, ldr=640)),                 # the image cannot carry a residual
+                     (_lib.FFN_BF16X3, desc(flags=_lib.IG_OUT_KV64 | _lib.IG_OUT_TRANSPOSED, N=320, ldo=4096 + 8, kv64_from=0))):      # row stride not whole blocks
+        assert lib.ffn_igemm(None, dtype, ctypes.byref(d)) == -22
+        assert b"KV64" in lib.ffn_last_error(), lib.ffn_last_error()
+
+
+def test_kv_images_eligibility_rules():
+    """ops.kv_images_ok: which self-attention calls may take K / V^T as the pre-split images their projections write (shapes of the one-wave-per-SIMD kernel, no
+    degenerate uniform-softmax entry in the plan, buffers the kernels' 32-bit offsets reach)."""
+    from freefine_amd import _lib, ops
+    km = object()
+    ok = [[ops.AttnEntrySpec(0, 1, 0.0, 1.0, kmask=km), ops.AttnEntrySpec(1, 1, 1.0, -1.0)]]
+    uni = [[ops.AttnEntrySpec(0, 0, 1.0, 0.0, kmask=km, flags=_lib.ATT_UNIFORM_SEL0)]]
+    skipped = [[ops.AttnEntrySpec(0, 0, 0.0, 0.0, kmask=km, flags=_lib.ATT_UNIFORM_SEL1), None]]        # an inactive term does not count
+    assert ops.kv_images_ok(64, 4096, 4096) and ops.kv_images_ok(64, 128, 128, ok) and ops.kv_images_ok(64, 1024, 1024, skipped)
+    assert not ops.kv_images_ok(64, 1024, 1024, uni)
+    assert not ops.kv_images_ok(40, 4096, 4096) and not ops.kv_images_ok(64, 64, 64) and not ops.kv_images_ok(64, 4096, 77)
+    assert not ops.kv_images_ok(64, 4096, 4096, None, 2 ** 31)
