@@ -273,7 +273,8 @@ static bool pp_ok(const ffn_igemm_desc& d, int bm, int bn, int splitk = 1) {
     // K tiles of the kernel: 64 bf16 elements; split-bf16 (d.K = the virtual 3 K): one 128-byte block [hi(32) | lo(32)] = 32 real elements
     const int nkt = d.x3 ? d.K / 96 : d.K / 64;
     // the 128-column tile exists for unsplit split-bf16 3x3 convolutions with a plain / residual epilogue only
-    if (bn == 128 && (bm != 256 || !d.x3 || d.conv != 1 || splitk > 1 || (d.flags & (FFN_IG_GEGLU | FFN_IG_OUT_PAIR | FFN_IG_OUT_KV64 | FFN_IG_OUT_TRANSPOSED)))) return false;
+    // (and only where neither wider tile divides N: the UNet's N = 640 / 1280 convolutions keep their 320- / 256-column tiles, no extra tuner candidate there)
+    if (bn == 128 && (bm != 256 || !d.x3 || d.conv != 1 || splitk > 1 || d.N % 256 == 0 || d.N % 320 == 0 || (d.flags & (FFN_IG_GEGLU | FFN_IG_OUT_PAIR | FFN_IG_OUT_KV64 | FFN_IG_OUT_TRANSPOSED)))) return false;
     if (d.x3) {
         if (d.x3 != 2 || d.K % 96 != 0 || d.a_lo != 32) return false;             // blocked operands only
     } else if (d.K % 64 != 0) return false;
