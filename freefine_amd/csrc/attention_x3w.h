@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void attn_x3w_kernel(const AttnParams p) {
     constexpr int D = 64, KT = 64;
     constexpr int KBLK = 2 * 4096;                              // one K block slot: 32 rows x 128 B, hi image | lo image
     constexpr int VIMG = 64 * 128, VSLOT = 2 * VIMG;            // one V^T tile slot: 64 rows (d) x 128 B (64 keys), hi image | lo image
-    constexpr int NKB = X3W_KRING, AHEAD = X3W_KRING == 6 ? 2 : 1;                                      // K ring: 6 block slots (a block is requested two iterations = four blocks ahead of its first read)
+    constexpr int NKB = X3W_KRING, AHEAD = X3W_KRING == 6 ? 2 : 1;                                      // K ring: X3W_KRING block slots; a block is requested AHEAD iterations (= 2 AHEAD blocks) ahead of the iteration that reads it
     constexpr int OFF_V = NKB * KBLK, OFF_M = OFF_V + 2 * VSLOT, OFF_TOT = OFF_M + 1024;   // K ring | V^T ring of 2 tiles | key-mask bytes 4 x 256 | multi-pass sums 64 KB
     constexpr int OOB = (int)0x80000000;
     constexpr float FAST_THR = 6.0f;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void attn_x3w_kernel(const AttnParams p) {
             }
         };
 
-        // ---- prologue: K blocks 0 .. 4, V^T(0), mask bytes of tiles 0 .. 2 staged; unit 0's scores and softmax un-overlapped ------------
+        // ---- prologue: K blocks 0 .. 2 AHEAD, V^T(0), mask bytes of tiles 0 .. AHEAD staged; unit 0's scores and softmax un-overlapped ------------
 #pragma unroll
         for (int bk = 0; bk < 2 * AHEAD + 1; ++bk) { dma_kblk(bk, bk < 2 * ntiles, 0); dma_kblk(bk, bk < 2 * ntiles, 1); }
         dma_v(0, 0); dma_v(0, 1); dma_v(0, 2); dma_v(0, 3);
@@ -530,13 +530,14 @@ __global__ __launch_bounds__(256) void attn_x3w_kernel(const AttnParams p) {
         }
         typedef std::integral_constant<int, AHEAD == 2> PRE;    // fragments of the next K block requested across the step / iteration boundary
 
-        // Hazards (iteration t = one barrier interval = units 2 t, 2 t + 1): it reads K blocks 2 t + 1, 2 t + 2 (and, ahead of the barrier that ends
-        // it, the first fragments of block 2 t + 3), the mask bytes of tiles t, t + 1 and V^T(t) -- all complete since the barrier that started
-        // it (K block 2 t + 3: requested in iteration t - 1).  It requests K blocks 2 t + 5, 2 t + 6 (ring of 6: the slots of blocks 2 t - 1, 2 t,
-        // last read in iteration t - 1), V^T(t + 1) (slot of V^T(t - 1)) and the mask bytes of tile t + 3 (slot of tile t - 1), one request per
-        // vector-free MFMA gap; every wave waits for its own pieces (vmcnt(0)) before the barrier that ends the iteration.  Requests past the end
-        // of the keys go out with an out-of-range offset (zeros into a slot nobody reads): no branch in the loop.  No LDS wait at the barrier:
-        // every fragment read except the four requested for the next iteration has been consumed by an MFMA.
+        // Hazards (iteration t = one barrier interval = units 2 t, 2 t + 1): it reads K blocks 2 t + 1, 2 t + 2, the mask bytes of tiles t, t + 1 and V^T(t) -- all
+        // complete since the barrier that started it (every wave waits for its own LDS-DMA pieces, vmcnt(0), before the barrier that ends an iteration).
+        // Shipped form (ring of 4, AHEAD = 1): at its START it requests K blocks 2 t + 3, 2 t + 4 (the slots of blocks 2 t - 1, 2 t, last read in iteration t - 1),
+        // V^T(t + 1) (slot of V^T(t - 1)) and the mask bytes of tile t + 2 (slot of tile t - 2).  Ring of 6 (X3W_KRING = 6, AHEAD = 2; measured slower): blocks
+        // 2 t + 5, 2 t + 6 and the mask bytes of tile t + 3, and the first fragments of block 2 t + 3 are read ahead of the barrier that ends the iteration.
+        // X3W_SPREAD = 1 puts one request into each vector-free MFMA gap instead of the iteration's start (also slower).  Requests past the end of the keys go out
+        // with an out-of-range offset (zeros into a slot nobody reads): no branch in the loop.  No LDS wait at the barrier: every fragment read (except, ring of 6,
+        // the four requested for the next iteration) has been consumed by an MFMA.
         int t = 0;
         for (; t + 1 < ntiles; ++t) {
             const int koffA = ((2 * t + 1) % NKB) * KBLK, koffB = ((2 * t + 2) % NKB) * KBLK, koffN = ((2 * t + 3) % NKB) * KBLK, voff = OFF_V + (t & 1) * VSLOT;
