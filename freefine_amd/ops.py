@@ -512,6 +512,25 @@ def kv_images_ok(Dh, S, Sk, passes=None, nbytes=0):
     return True
 
 
+_ROWSPLIT = os.environ.get("FFN_ATT_ROWSPLIT", "1") != "0"
+_CUS = {}
+
+
+def attn_row_split(Bo, wg_per_row, maxb, cus):
+    """output rows per launch of a self-attention call on the one-workgroup-per-CU kernels (attn_x3w / attn_x3p / attn_pp: a (row, head, 256-query block)
+    workgroup each, `cus` of them resident at a time): the uniform chunk n <= maxb that minimises the number of resident ROUNDS
+    sum_i ceil(n_i * wg_per_row / cus) over the call's launches (launches of one stream do not overlap: every launch pays its own partly filled last
+    round); ties go to the larger chunk (fewer launches).  72 rows: S = 4096, 5 heads (80 workgroups per row) 16 + 16 + 16 + 16 + 8 = 23 rounds (as
+    before); S = 1024, 10 heads (40 per row) 6 x 12 = 12 rounds instead of 14; S = 256, 20 heads (20 per row) 6 x 12 = 6 rounds instead of 9."""
+    best_n, best = min(maxb, Bo), None
+    for n in range(min(maxb, Bo), 0, -1):
+        full, rest = divmod(Bo, n)
+        rounds = full * -(-n * wg_per_row // cus) + (-(-rest * wg_per_row // cus) if rest else 0)
+        if best is None or rounds < best:
+            best_n, best = n, rounds
+    return best_n
+
+
 def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=None, Bo=None, C=None, x3=False, out_pair=False, kv_images=False):
     """q: [Bq,S,C]; k: [Bk,Sk,C]; vt: [Bk,C,ldvt] (V transposed).  passes: list (per pass) of lists (per output
     row) of AttnEntrySpec or None (= skipped).  passes=None -> plain attention, row b uses its own K/V.
@@ -536,8 +555,14 @@ def attention(q, k, vt, heads, scale, passes=None, *, Sk=None, out=None, w_dev=N
     esz = q.element_size()
     dcode = L.FFN_BF16X3 if (x3 and q.dtype == torch.float32) else _dt(q)      # split-bf16 arithmetic on fp32 operands
     descs = []
-    for b0 in range(0, Bo, L.ATT_MAXB):
-        nb = min(L.ATT_MAXB, Bo - b0)
+    chunk = L.ATT_MAXB
+    if _ROWSPLIT and Bo > 1 and Dh == 64 and S >= 128 and Sk % 64 == 0 and q.is_cuda:      # the 256-queries-per-workgroup, one-workgroup-per-CU kernels
+        di = q.device.index if q.device.index is not None else torch.cuda.current_device()
+        if di not in _CUS:
+            _CUS[di] = torch.cuda.get_device_properties(di).multi_processor_count
+        chunk = attn_row_split(Bo, heads * -(-S // 256), L.ATT_MAXB, _CUS[di])
+    for b0 in range(0, Bo, chunk):
+        nb = min(chunk, Bo - b0)
         d = L.AttnDesc()
         d.q, d.k, d.vt, d.w_dev = q.data_ptr(), k.data_ptr(), vt.data_ptr(), _p(w_dev)
         d.out = out.data_ptr() + b0 * S * Cq * esz       # (pair rows: 2 Cq bf16 = Cq fp32 worth of bytes)

@@ -146,3 +146,22 @@ def test_kv_images_eligibility_rules():
     assert not ops.kv_images_ok(64, 1024, 1024, uni)
     assert not ops.kv_images_ok(40, 4096, 4096) and not ops.kv_images_ok(64, 64, 64) and not ops.kv_images_ok(64, 4096, 77)
     assert not ops.kv_images_ok(64, 4096, 4096, None, 2 ** 31)
+
+
+def test_attention_row_split_minimises_resident_rounds():
+    """ops.attn_row_split: rows per launch of a self-attention call on the one-workgroup-per-CU kernels (256 CUs): never more than FFN_ATT_MAXB, never more rounds
+    than the fixed 16-row split, the documented cases, every row covered once."""
+    from freefine_amd import _lib, ops
+    M = _lib.ATT_MAXB
+
+    def rounds(Bo, w, n, cus=256):
+        full, rest = divmod(Bo, n)
+        return full * -(-n * w // cus) + (-(-rest * w // cus) if rest else 0)
+    assert ops.attn_row_split(72, 80, M, 256) == 16 and rounds(72, 80, 16) == 23
+    assert ops.attn_row_split(72, 40, M, 256) == 12 and rounds(72, 40, 12) == 12 and rounds(72, 40, 16) == 14
+    assert ops.attn_row_split(72, 20, M, 256) == 12 and rounds(72, 20, 12) == 6 and rounds(72, 20, 16) == 9
+    assert ops.attn_row_split(48, 80, M, 256) == 16
+    for Bo in (1, 2, 3, 7, 16, 17, 24, 48, 72, 96, 100):
+        for w in (5, 20, 40, 80, 180):
+            n = ops.attn_row_split(Bo, w, M, 256)
+            assert 1 <= n <= min(M, Bo) and rounds(Bo, w, n) <= rounds(Bo, w, min(M, Bo))
