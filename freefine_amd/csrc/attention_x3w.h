@@ -45,6 +45,9 @@ typedef __attribute__((address_space(3))) uint8_t x3w_lds_u8_t;
                       // exponentials.  Measured SLOWER on one box (profiles/r6_x3w_row_sums_in_phase1_ab.txt: 1461 vs 1412 us two-pass S = 4096, 832 vs 815 one-pass):
                       // the phase-1 gaps (four split instructions + the fragment reads' issue) have no slack either.  Kept for the A/B only.
 #endif
+#ifndef X3W_PKSUB
+#define X3W_PKSUB 0   // 1: the two subtractions of a P-split pair (lo = x - hi) as ONE packed v_pk_add_f32 -- measured SLOWER (1448 vs 1382 us, profiles/r6_x3w_packed_split_sub_ab.txt); A/B only
+#endif
 #ifndef X3W_ABL
 #define X3W_ABL 0     // timing-only ablations (tools/native/x3w_bench.hip): 1 no softmax / split VALU, 2 no LDS-DMA in the loop, 3 no MFMA
 #endif
@@ -375,7 +378,16 @@ __global__ __launch_bounds__(256) void attn_x3w_kernel(const AttnParams p) {
             float d0[4], d1[4];
             auto S1 = [&](int i) { hw[i] = pack_bf16x2(x[8 * sp + 2 * i], x[8 * sp + 2 * i + 1]); };
             auto S2 = [&](int i) {
-                d0[i] = x[8 * sp + 2 * i] - __uint_as_float(hw[i] << 16); d1[i] = x[8 * sp + 2 * i + 1] - __uint_as_float(hw[i] & 0xffff0000u);
+                if (X3W_PKSUB) {
+                    typedef float x3w_f32x2 __attribute__((ext_vector_type(2)));
+                    const x3w_f32x2 xv = {x[8 * sp + 2 * i], x[8 * sp + 2 * i + 1]};
+                    const x3w_f32x2 hv = {__uint_as_float(hw[i] << 16), __uint_as_float(hw[i] & 0xffff0000u)};
+                    x3w_f32x2 dv;                                // (written as `xv - hv` the compiler scalarises it again: two v_add_f32_e64 with neg modifiers)
+                    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dv) : "v"(xv), "v"(hv));
+                    d0[i] = dv[0]; d1[i] = dv[1];
+                } else {
+                    d0[i] = x[8 * sp + 2 * i] - __uint_as_float(hw[i] << 16); d1[i] = x[8 * sp + 2 * i + 1] - __uint_as_float(hw[i] & 0xffff0000u);
+                }
                 if (X3W_SUMP1) {                                 // the row sums of cu, two adds per gap, pinned to it (otherwise sunk to the end of the step)
                     lp[qp][0] += x[8 * sp + 2 * i]; lp[qp][1] += x[8 * sp + 2 * i + 1];
                     asm volatile("" : "+v"(lp[qp][0]), "+v"(lp[qp][1]));
